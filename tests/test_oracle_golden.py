@@ -1,0 +1,122 @@
+"""Pins oracle/cosine_sim_oracle.py against golden vectors produced by the REFERENCE
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import cases as C
+from oracle import cosine_sim_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _np(t):
+    return None if t is None else t.double().numpy() if t.is_floating_point() else t.numpy()
+
+
+def _load(case):
+    inp = {k: _np(v) for k, v in C.make_inputs(case).items()}
+    gold = dict(np.load(os.path.join(GOLD, case["name"] + ".npz")))
+    return inp, gold
+
+
+def _valid_rows(case, inp):
+    """[B,1,N] (or [B,N] merged) bool: rows with at least one valid key."""
+    n, m, b = case["n"], case["m"], case["b"]
+    ok = np.ones((b, n), dtype=bool)
+    if case["causal"]:
+        ok &= (np.arange(n)[None, :] + (m - n)) >= 0
+    if inp["mask"] is not None:
+        ok &= inp["mask"].any(-1)[:, None]
+    return ok if case["merged"] else ok[:, None, :]
+
+
+@pytest.mark.parametrize("case", C.CASES, ids=lambda c: c["name"])
+def test_plain_forward_matches_reference(case):
+    inp, gold = _load(case)
+    o = O.plain_attention(inp["q"], inp["k"], inp["v"], mask=inp["mask"], attn_bias=inp["attn_bias"], **C.op_kwargs(case))
+    assert o.shape == gold["o_plain"].shape
+    assert np.abs(o - gold["o_plain"]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("case", C.CASES, ids=lambda c: c["name"])
+def test_kernel_form_forward_matches_reference_on_nonempty_rows(case):
+    """exp(S - scale) / rowsum form (cu:1216-1246) == softmax form wherever a row has a valid key;
+    rows without one are 0 (kernel semantics)."""
+    inp, gold = _load(case)
+    o, inv_l = O.attention_forward_stats(inp["q"], inp["k"], inp["v"], mask=inp["mask"], attn_bias=inp["attn_bias"],
+                                         **C.op_kwargs(case))
+    ok = _valid_rows(case, inp)
+    okb = np.broadcast_to(ok[..., None], o.shape)
+    assert np.abs(np.where(okb, o - gold["o_plain"], 0.0)).max() <= 2e-6
+    assert np.abs(np.where(okb, 0.0, o)).max() == 0.0
+    assert np.isfinite(inv_l).all()
+
+
+@pytest.mark.parametrize("case", [c for c in C.CASES if c["tiled_ok"]], ids=lambda c: c["name"])
+def test_tiled_forward_matches_reference_cpu_path(case):
+    inp, gold = _load(case)
+    kw = C.op_kwargs(case)
+    q, k = inp["q"], inp["k"]
+    if kw["l2norm_qk"]:
+        q, k = O.l2norm(q, kw["groups"]), O.l2norm(k, kw["groups"])
+    for tile in (512, 64):
+        o = O.tiled_attention(q, k, inp["v"], mask=inp["mask"], attn_bias=inp["attn_bias"], scale=kw["scale"],
+                              causal=kw["causal"], attn_bias_batch_dim=kw["attn_bias_batch_dim"],
+                              row_tile=tile, col_tile=tile)
+        assert np.abs(o - gold["o_tiled"]).max() <= 2e-5     # reference computes this path in f32
+
+
+@pytest.mark.parametrize("case", C.CASES, ids=lambda c: c["name"])
+def test_backward_matches_reference_autograd(case):
+    inp, gold = _load(case)
+    dq, dk, dv, db = O.attention_backward(inp["do"], inp["q"], inp["k"], inp["v"], mask=inp["mask"],
+                                          attn_bias=inp["attn_bias"], **C.op_kwargs(case))
+    ok = _valid_rows(case, inp)
+    empty = not ok.all()
+    okq = np.broadcast_to(ok[..., None], dq.shape)
+    tol = 5e-6
+    assert np.abs(np.where(okq, dq - gold["dq"], 0.0)).max() <= tol * max(1.0, np.abs(gold["dq"]).max())
+    if not empty:
+        # rows with no valid key: plain's softmax is uniform there and feeds dv / d_bias; the kernel form gives 0
+        assert np.abs(dv - gold["dv"]).max() <= tol * max(1.0, np.abs(gold["dv"]).max())
+        assert np.abs(dk - gold["dk"]).max() <= tol * max(1.0, np.abs(gold["dk"]).max())
+        if db is not None:
+            assert np.abs(db - gold["db"]).max() <= tol * max(1.0, np.abs(gold["db"]).max())
+    else:
+        assert np.abs(dk - gold["dk"]).max() <= tol * max(1.0, np.abs(gold["dk"]).max())
+
+
+@pytest.mark.parametrize("case", [c for c in C.CASES if c["name"][:3] in ("g01", "g12", "g16", "g17")],
+                         ids=lambda c: c["name"])
+def test_l2norm_matches_reference(case):
+    inp, gold = _load(case)
+    assert np.abs(O.l2norm(inp["q"], case["groups"]) - gold["qn"]).max() <= 1e-6
+    assert np.abs(O.l2norm(inp["k"], case["groups"]) - gold["kn"]).max() <= 1e-6
+
+
+def test_l2norm_backward_finite_difference():
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((3, 5, 12))
+    g = rs.standard_normal((3, 5, 12))
+    for groups in (1, 3):
+        ana = O.l2norm_backward(g, x, groups)
+        num = np.zeros_like(x)
+        eps = 1e-6
+        it = np.nditer(x, flags=["multi_index"])
+        for _ in it:
+            i = it.multi_index
+            xp, xm = x.copy(), x.copy()
+            xp[i] += eps
+            xm[i] -= eps
+            num[i] = ((O.l2norm(xp, groups) - O.l2norm(xm, groups)) * g).sum() / (2 * eps)
+        assert np.abs(ana - num).max() < 1e-6
+
+
+def test_flop_convention():
+    # C3 = (4,8,4096,4096,64) causal fwd+bwd = 240.58 GFLOP; dense 481.04
+    assert abs(O.algorithmic_flops(4, 8, 4096, 4096, 64) / 1e9 - 481.04) < 0.01
+    assert abs(O.algorithmic_flops(4, 8, 4096, 4096, 64, causal=True) / 1e9 - 240.58) < 0.01
+    assert O.causal_valid_count(4, 6) == 3 + 4 + 5 + 6
+    assert O.causal_valid_count(3, 2) == 0 + 1 + 2
