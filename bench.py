@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward + backward of flash_cosine_sim_attention on one batch of synthetic
+input at the configuration the metric is quoted on (BASELINE.json configs[2] / SURVEY "C3"):
+    q, k, v ~ N(0,1), shape (B=4, H=8, N=4096, D=64), bf16, causal=True, scale=8, groups=1,
+    l2norm_qk=True; backward driven by a fixed random dO (inputs resident in HBM).
+For N > 1 GPUs (launched with torch.distributed.run, one rank per GPU) every rank runs the same
+per-GPU workload -- the op is embarrassingly parallel over (batch, head), there is no collective on the
+data path ("replicas only") -- so scaling is "weak" and `value` is the
+sum over ranks of algorithmic FLOPs / max-over-ranks time.
+
+FLOP convention: GEMM FLOPs only, fwd 4*B*H*N*M*D, bwd 10*B*H*N*M*D, times the causal
+fraction n_valid/(N*M).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = dict(name="C3 fwd+bwd (4,8,4096,64) bf16 causal", B=4, H=8, N=4096, M=4096, D=64,
+                dtype="bf16", causal=True, scale=8.0, groups=1)
+MFMA_PEAK_TFLOPS = 2500.0         # dense bf16/f16 MFMA peak, MI355X_MICROARCH.md (AMD figure excl. sparsity)
+
+
+def causal_fraction(n, m):
+    diff = m - n
+    nv = sum(min(m, max(0, i + diff + 1)) for i in range(n))
+    return nv / float(n * m)
+
+
+def flops(w, fwd=True, bwd=True):
+    per = (4 if fwd else 0) + (10 if bwd else 0)
+    f = per * w["B"] * w["H"] * w["N"] * w["M"] * w["D"]
+    return f * (causal_fraction(w["N"], w["M"]) if w["causal"] else 1.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)      # reference protocol: mean of 20 (benchmark.py:26)
+    ap.add_argument("--warmup", type=int, default=10)     # reference protocol: 10 warm-ups (benchmark.py:11)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the instrumented pass for the roofline object")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible; bench.py measures the HIP path only"}))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import flash_cosine_sim_attention_amd as F
+    from flash_cosine_sim_attention_amd import _lib
+
+    w = WORKLOAD
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(rank)
+    shp = (w["B"], w["H"], w["N"], w["D"])
+    q, k, v = (torch.randn(shp, device="cuda", dtype=dt, generator=g).requires_grad_() for _ in range(3))
+    do = torch.randn(shp, device="cuda", dtype=dt, generator=g)
+
+    def step():
+        q.grad = k.grad = v.grad = None
+        o = F.flash_cosine_sim_attention(q, k, v, causal=w["causal"], scale=w["scale"], groups=w["groups"])
+        o.backward(do)
+        return o
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_flops = flops(w) * world
+    value = total_flops / (ms_per_step * 1e-3) / 1e12
+
+    # ---- roofline: dominant kernel, timed with HIP events on the launch stream (library hook) ----------
+    roofline = None
+    kernels = None
+    if rank == 0 and not args.no_kernel_events:
+        _lib.profile_enable(True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        stats = _lib.profile_collect()
+        kernels = {s["name"]: dict(calls=s["calls"], avg_us=round(s["total_ms"] / max(s["calls"], 1) * 1e3, 2),
+                                   per_step_us=round(s["total_ms"] / args.steps * 1e3, 2)) for s in stats}
+        # algorithmic GEMM FLOPs each attention kernel is responsible for, per launch:
+        #   fwd: QK^T + PV = 4 BHNMD;  bwd_dkv: S, dP, dV, dK = 8 BHNMD;  bwd_dq: dQ = 2 BHNMD (its S/dP recompute
+        #   is not algorithmic work).  All times the causal fraction.
+        unit = w["B"] * w["H"] * w["N"] * w["M"] * w["D"] * (causal_fraction(w["N"], w["M"]) if w["causal"] else 1.0)
+        alg = {"fwd": 4 * unit, "bwd_dkv": 8 * unit, "bwd_dq": 2 * unit}
+        cand = [s for s in stats if s["name"] in alg]
+        if cand:
+            dom = max(cand, key=lambda s: s["total_ms"])
+            avg_s = dom["total_ms"] / dom["calls"] * 1e-3
+            ach = alg[dom["name"]] / avg_s / 1e12
+            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_gflop_per_launch": round(alg[dom["name"]] / 1e9, 2),
+                        "timing": "hipEvent pairs recorded by libfcsa_hip on the launch stream over %d steps" % args.steps}
+
+    # ---- max |delta| vs a PyTorch f32 evaluation of the same math on (b,h) slices ----------------------
+    max_delta = None
+    if rank == 0:
+        with torch.no_grad():
+            o = F.flash_cosine_sim_attention(q, k, v, causal=w["causal"], scale=w["scale"])
+            md = 0.0
+            for (b, h) in ((0, 0), (w["B"] - 1, w["H"] - 1)):
+                qs, ks, vs = q[b, h].float(), k[b, h].float(), v[b, h].float()
+                s = torch.nn.functional.normalize(qs, dim=-1) @ torch.nn.functional.normalize(ks, dim=-1).t() * w["scale"]
+                s = s.masked_fill(torch.ones_like(s, dtype=torch.bool).triu(1), float("-inf"))
+                ref = torch.softmax(s, -1) @ vs
+                md = max(md, (o[b, h].float() - ref).abs().max().item())
+            max_delta = md
+
+    # ---- CPU baseline: the PyTorch port of the reference's plain attention on the host cores -----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_cpu_port as P
+        sample = (1, w["H"], w["N"], w["D"])                 # one batch element of the same workload
+        secs = P.time_fwd_bwd(sample, sample, dt, causal=w["causal"], scale=w["scale"], reps=2)
+        wf = dict(w, B=1)
+        cpu = {"value": round(flops(wf) / secs / 1e12, 4), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": "1 of 4 batch elements of the workload: (1,8,4096,64) bf16 causal fwd+bwd, "
+               "PyTorch CPU port of plain_cosine_sim_attention + autograd, best of 2 after 1 warm-up (%.2f s)" % secs}
+
+    if rank == 0:
+        out = {
+            "metric": "attention TFLOP/s fwd+bwd (B=4,H=8,N=4096,D=64 bf16) + max-|delta| vs PyTorch ref",
+            "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": w["name"], "causal": True, "scale": 8, "groups": 1, "l2norm_qk": True,
+                       "per_gpu_batch": w["B"], "parallelism": "replicas x%d (no collective)" % world,
+                       "flop_convention": "GEMM only: fwd 4*BHNMD + bwd 10*BHNMD, x causal fraction 4097/8192",
+                       "algorithmic_gflop_per_step_per_gpu": round(flops(w) / 1e9, 2)},
+            "max_abs_delta_vs_pytorch_f32": max_delta,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,445 @@
+// fcsa_bwd.hip -- backward kernels of fused cosine-similarity attention for gfx950 (f16 / bf16).
+//
+// Replaces backward_preprocess (reference cu:1256-1335) and backward_kernel (cu:1339-1626).
+// Math, with Qh/Kh the normalised inputs:
+//     delta = rowsum(dO * O);  P = exp(S - shift) * inv_l;  dV = P^T dO;  dP = dO V^T;
+//     dS = P * (dP - delta)  (= d_bias);  dQh = scale * dS Kh;  dKh = scale * dS^T Qh
+//
+// The reference runs ONE key-tile-parallel kernel and pushes dQ through f32 global atomics
+// (cu:1610) after a one-row-per-block delta kernel (cu:1842-1850).  Here the work is split so
+// that nothing needs atomics and every accumulator lives in registers of the wave that owns it:
+//
+//   bwd_dq_kernel  : query-row parallel (same skeleton as the forward kernel).  Prologue computes
+//                    delta for its own rows in registers (no separate kernel) and publishes it;
+//                    loop: S^T = K Q^T, dP^T = V dO^T, dS^T, dQ^T += K^T dS^T.
+//   bwd_dkv_kernel : key-row parallel.  K/V fragments of the wave's 32 keys stay in VGPRs; Q and dO
+//                    tiles stream through LDS; S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+//                    Writes one [M, D] slab per (batch, q-head); with single-headed K/V the slabs are
+//                    reduced over heads by the finalize kernel (fcsa_norm.hip) instead of the
+//                    reference's f32 atomics (cu:1613-1619).
+//
+// 7 tile products instead of the reference's 5 (S and dP are recomputed in both kernels); results
+// are deterministic.  d_bias (optional path) is accumulated with f32 atomics like cu:1574-1576.
+#include "fcsa_common.cuh"
+#include "fcsa_kernels.h"
+
+namespace fcsa {
+
+template <typename T, int D>
+FCSA_DEV void store_row_tile(char* row, const f32x16 (&acc)[TileGeom<D>::DB], float mul, int hi, bool as_f32) {
+  typedef Traits<T> TR;
+  // lane (row, hi) holds features 32*db + 8*rq + 4*hi + 0..3
+#pragma unroll
+  for (int db = 0; db < TileGeom<D>::DB; ++db)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      if (32 * db + 8 * rq < D) {
+        const int d0 = 32 * db + 8 * rq + 4 * hi;
+        if (as_f32) {
+          f32x4 v = {acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul, acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul};
+          *reinterpret_cast<f32x4*>(row + d0 * 4) = v;
+        } else {
+          u32x2 v;
+          v[0] = TR::pack2(acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul);
+          v[1] = TR::pack2(acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul);
+          *reinterpret_cast<u32x2*>(row + d0 * 2) = v;
+        }
+      }
+    }
+}
+
+// =============================================================================================
+// dQ kernel
+// =============================================================================================
+template <typename T, int D, bool MASKED>
+FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<D>& fa, const u32x4 (&qf)[TileGeom<D>::KS],
+                      const u32x4 (&dof)[TileGeom<D>::KS], f32x16 (&dq)[TileGeom<D>::DB], float lc, float delta,
+                      const BwdParams& p, uint64_t word, int i, int j0, int diff, const char* bias_row, float* dbias_row) {
+  typedef TileGeom<D> G;
+  typedef Traits<T> TR;
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(vt, 32 * jb, kk), dof[kk], dp);
+
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED) {
+      w = (uint32_t)(word >> (32 * jb)) >> (4 * fa.hi);
+      if (p.causal) w &= le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi));
+    }
+    const int jbase = j0 + 32 * jb + 4 * fa.hi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float x = s[r] * p.c1 + lc;
+      const int j = jbase + crow(r, 0);
+      if (bias_row != nullptr && j < p.M) {
+        const typename TR::elem bv = reinterpret_cast<const typename TR::elem*>(bias_row)[j];
+        x += (float)bv * p.bias_c;
+      }
+      float e = fast_exp2(x);
+      if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
+      const float ds = e * (dp[r] - delta);
+      if (dbias_row != nullptr && j < p.M && ds != 0.f) atomicAdd(dbias_row + j, ds);   // cu:1574-1576
+      s[r] = ds;
+    }
+    const u32x4 pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 1);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      dq[db] = TR::mfma32(fa.tr_frag(kt, 32 * jb, db), pb0, dq[db]);
+      dq[db] = TR::mfma32(fa.tr_frag(kt, 32 * jb + 16, db), pb1, dq[db]);
+    }
+  }
+}
+
+template <typename T, int D, int NW>
+__global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+  typedef TileGeom<D> G;
+  typedef Traits<T> TR;
+  constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
+  constexpr int TILE_B = BN * G::ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FragAddr<D> fa;
+  fa.init(lane);
+
+  const int MT = (p.N + BM - 1) / BM;
+  int bh, mt;
+  block_to_work(blockIdx.x, p.B * p.H, MT, bh, mt);
+  if (p.causal) mt = MT - 1 - mt;
+  const int b = bh / p.H, h = bh % p.H;
+  const int m0 = mt * BM;
+  const int mw = m0 + wave * 32;
+  const int i = mw + (lane & 31);
+  const int diff = p.M - p.N;
+
+  int last_key = p.M - 1;
+  if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
+  const int nt = last_key < 0 ? 0 : last_key / BN + 1;
+
+  // Q, dO fragments (B operands) and delta = <dO_i, O_i>  (replaces backward_preprocess, cu:1256-1335)
+  u32x4 qf[G::KS], dof[G::KS];
+  float delta = 0.f, lc = 0.f;
+  {
+    const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+    const char* dorow = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh + (int64_t)i * p.d_out.sn;
+    const char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      qf[kk] = z;
+      dof[kk] = z;
+      if (i < p.N) {
+        qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+        dof[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
+        const u32x4 of = *reinterpret_cast<const u32x4*>(orow + (2 * kk + fa.hi) * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) delta += TR::lo(dof[kk][e]) * TR::lo(of[e]) + TR::hi(dof[kk][e]) * TR::hi(of[e]);
+      }
+    }
+    delta = xhalf_sum(delta);
+    if (i < p.N) {
+      const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
+      lc = __builtin_amdgcn_logf(p.inv_l[ridx]) - p.c2;     // v_log_f32 = log2
+      if (fa.hi == 0) p.delta[ridx] = delta;
+    }
+  }
+
+  f32x16 dq[G::DB];
+#pragma unroll
+  for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
+  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
+  const char* bias_row = nullptr;
+  float* dbias_row = nullptr;
+  if (i < p.N) {
+    const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + i) * (int64_t)p.M;
+    if (p.bias != nullptr) bias_row = p.bias + boff * (int64_t)sizeof(typename TR::elem);
+    if (p.d_bias != nullptr) dbias_row = p.d_bias + boff;
+  }
+
+  Stager<D, BN, NT> sk, sv;
+  uint8_t mb = 1;
+  if (nt > 0) {
+    sk.load(kbase, p.k.sn, p.M, tid);
+    sv.load(vbase, p.v.sn, p.M, tid);
+    if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
+    sk.store(smem, tid);
+    sv.store(smem + TILE_B, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * BN;
+    const char* kcur = smem + (t & 1) * 2 * TILE_B;
+    const char* vcur = kcur + TILE_B;
+    char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+    const bool more = t + 1 < nt;
+    if (more) {
+      sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
+      sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
+    }
+    const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);
+    if (mrow && more) {
+      const int key = j0 + BN + lane;
+      mb = key < p.M ? mrow[key] : (uint8_t)0;
+    }
+    const bool skip = p.causal && (j0 > mw + 31 + diff);
+    const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
+    if (!skip) {
+      if (masked) dq_tile<T, D, true>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
+      else        dq_tile<T, D, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
+    }
+    if (more) {
+      sk.store(knxt, tid);
+      sv.store(knxt + TILE_B, tid);
+    }
+    __syncthreads();
+  }
+
+  if (i < p.N) {
+    char* row = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)i * p.dq.sn;
+    store_row_tile<T, D>(row, dq, p.scale, fa.hi, p.dq_f32 != 0);     // cu:1580-1582: dS *= scale
+  }
+}
+
+// =============================================================================================
+// dK / dV kernel
+// =============================================================================================
+template <typename T, int D, bool MASKED>
+FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<D>& fa,
+                       const u32x4 (&kf)[TileGeom<D>::KS], const u32x4 (&vf)[TileGeom<D>::KS],
+                       f32x16 (&dk)[TileGeom<D>::DB], f32x16 (&dv)[TileGeom<D>::DB], const BwdParams& p,
+                       bool key_ok, int j, int i0, int diff, int nib, const char* bias_col) {
+  typedef TileGeom<D> G;
+  typedef Traits<T> TR;
+  for (int ib = 0; ib < nib; ++ib) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), vf[kk], dp);
+
+    // query i of register r: i0 + 32*ib + crow(r, hi)
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED) {
+      w = key_ok ? 0xffffffffu : 0u;
+      if (p.causal) w &= ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi));   // valid iff i + diff >= j
+    }
+    f32x16 pr;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 lc4 = *reinterpret_cast<const f32x4*>(lcs + 32 * ib + 8 * rq + 4 * fa.hi);
+      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dls + 32 * ib + 8 * rq + 4 * fa.hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rq + e;
+        float x = s[r] * p.c1 + lc4[e];
+        if (bias_col != nullptr) {
+          const int i = i0 + 32 * ib + crow(r, 0) + 4 * fa.hi;
+          if (i < p.N) {
+            const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
+                bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
+            x += (float)bv * p.bias_c;
+          }
+        }
+        float pe = fast_exp2(x);
+        if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
+        pr[r] = pe;
+        s[r] = pe * (dp[r] - dl4[e]);
+      }
+    }
+    const u32x4 pp0 = pack8<T>(pr, 0), pp1 = pack8<T>(pr, 1);
+    const u32x4 pd0 = pack8<T>(s, 0), pd1 = pack8<T>(s, 1);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      dv[db] = TR::mfma32(fa.tr_frag(dot, 32 * ib, db), pp0, dv[db]);
+      dv[db] = TR::mfma32(fa.tr_frag(dot, 32 * ib + 16, db), pp1, dv[db]);
+      dk[db] = TR::mfma32(fa.tr_frag(qt, 32 * ib, db), pd0, dk[db]);
+      dk[db] = TR::mfma32(fa.tr_frag(qt, 32 * ib + 16, db), pd1, dk[db]);
+    }
+  }
+}
+
+template <typename T, int D, int NW, int BMQ>
+__global__ void __launch_bounds__(NW * 64, (D <= 32 ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+  typedef TileGeom<D> G;
+  typedef Traits<T> TR;
+  constexpr int BNK = 32 * NW, NT = NW * 64;
+  constexpr int TILE_B = BMQ * G::ROWB;
+  constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 4;                // Q tile | dO tile | lc[BMQ] | delta[BMQ]
+  static_assert(BMQ % 32 == 0 && BMQ <= NT, "query tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF_B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FragAddr<D> fa;
+  fa.init(lane);
+
+  const int KT = (p.M + BNK - 1) / BNK;
+  int bh, kt;
+  block_to_work(blockIdx.x, p.B * p.H, KT, bh, kt);     // causal: low key tiles are the heavy ones and come first
+  const int b = bh / p.H, h = bh % p.H;
+  const int n0 = kt * BNK;
+  const int nw = n0 + wave * 32;                        // first key of this wave
+  const int j = nw + (lane & 31);                       // this lane's key
+  const int diff = p.M - p.N;
+
+  // query tiles this workgroup needs: causal keeps i >= j - diff
+  const int QT = (p.N + BMQ - 1) / BMQ;
+  int t0 = 0;
+  if (p.causal) t0 = max(0, n0 - diff) / BMQ;
+
+  // K, V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T), kept for the whole loop
+  u32x4 kf[G::KS], vf[G::KS];
+  {
+    const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
+    const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j * p.v.sn;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      kf[kk] = z;
+      vf[kk] = z;
+      if (j < p.M) {
+        kf[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + fa.hi) * 16);
+        vf[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + fa.hi) * 16);
+      }
+    }
+  }
+  bool key_ok = j < p.M;
+  if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
+
+  f32x16 dk[G::DB], dv[G::DB];
+#pragma unroll
+  for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
+  const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
+  const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
+  const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
+  const char* bias_col = nullptr;
+  if (p.bias != nullptr && j < p.M)
+    bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + j) * (int64_t)sizeof(typename TR::elem);
+
+  Stager<D, BMQ, NT> sq, sdo;
+  float lc_r = 0.f, dl_r = 0.f;
+  auto load_tile = [&](int t) {
+    const int i0 = t * BMQ;
+    sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0, tid);
+    sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0, tid);
+    if (tid < BMQ) {
+      const int i = i0 + tid;
+      // rows beyond N: lc = -inf makes P exactly 0 there
+      lc_r = i < p.N ? __builtin_amdgcn_logf(invl_row[i]) - p.c2 : -INFINITY;
+      dl_r = i < p.N ? delta_row[i] : 0.f;
+    }
+  };
+  auto store_tile = [&](char* buf) {
+    sq.store(buf, tid);
+    sdo.store(buf + TILE_B, tid);
+    if (tid < BMQ) {
+      reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = lc_r;
+      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = dl_r;
+    }
+  };
+
+  if (t0 < QT) {
+    load_tile(t0);
+    store_tile(smem);
+  }
+  __syncthreads();
+
+  for (int t = t0; t < QT; ++t) {
+    const int i0 = t * BMQ;
+    const int par = (t - t0) & 1;
+    const char* cur = smem + par * BUF_B;
+    char* nxt = smem + (par ^ 1) * BUF_B;
+    const bool more = t + 1 < QT;
+    if (more) load_tile(t + 1);
+    const int nib = min(BMQ, p.N - i0 + 31) / 32;                       // 32-row blocks that contain real rows
+    const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
+    const bool masked = (p.mask != nullptr) || (n0 + BNK > p.M) || (p.causal && (i0 + diff < nw + 31));
+    if (!skip) {
+      const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
+      const float* dls = lcs + BMQ;
+      if (masked) dkv_tile<T, D, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
+      else        dkv_tile<T, D, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
+    }
+    if (more) store_tile(nxt);
+    __syncthreads();
+  }
+
+  if (j < p.M) {
+    char* dkrow = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)j * p.dk.sn;
+    char* dvrow = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)j * p.dv.sn;
+    store_row_tile<T, D>(dkrow, dk, p.scale, fa.hi, p.dk_f32 != 0);
+    store_row_tile<T, D>(dvrow, dv, 1.f, fa.hi, p.dv_f32 != 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+static hipError_t launch_dq_t(const BwdParams& p, hipStream_t s) {
+  constexpr int NW = 4, BM = 32 * NW;
+  const int MT = (p.N + BM - 1) / BM;
+  const size_t lds = 4 * 64 * TileGeom<D>::ROWB;
+  auto kern = bwd_dq_kernel<T, D, NW>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * MT)), dim3(NW * 64), lds, s, p);
+  return hipGetLastError();
+}
+
+template <typename T, int D>
+static hipError_t launch_dkv_t(const BwdParams& p, hipStream_t s) {
+  constexpr int NW = 4, BNK = 32 * NW, BMQ = 64;
+  const int KT = (p.M + BNK - 1) / BNK;
+  const size_t lds = 2 * (2 * BMQ * TileGeom<D>::ROWB + 2 * BMQ * 4);
+  auto kern = bwd_dkv_kernel<T, D, NW, BMQ>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * KT)), dim3(NW * 64), lds, s, p);
+  return hipGetLastError();
+}
+
+#define FCSA_DISPATCH_D(FN, T)                      \
+  switch (D) {                                      \
+    case 16:  return FN<T, 16>(p, s);               \
+    case 32:  return FN<T, 32>(p, s);               \
+    case 64:  return FN<T, 64>(p, s);               \
+    case 96:  return FN<T, 96>(p, s);               \
+    case 128: return FN<T, 128>(p, s);              \
+    default:  return hipErrorInvalidValue;          \
+  }
+
+hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s) {
+  if (p.B * p.H == 0 || p.N == 0) return hipSuccess;
+  if (dtype == 2) { FCSA_DISPATCH_D(launch_dq_t, BF16) }
+  if (dtype == 1) { FCSA_DISPATCH_D(launch_dq_t, F16) }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t s) {
+  if (p.B * p.H == 0 || p.M == 0) return hipSuccess;
+  if (dtype == 2) { FCSA_DISPATCH_D(launch_dkv_t, BF16) }
+  if (dtype == 1) { FCSA_DISPATCH_D(launch_dkv_t, F16) }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fcsa

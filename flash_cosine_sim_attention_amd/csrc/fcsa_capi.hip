@@ -1,0 +1,355 @@
+// fcsa_capi.hip -- the C ABI of libfcsa_hip.so (include/fcsa.h): validation, workspace carving and
+// launch sequencing.  Replaces the reference's host launchers + pybind module (cu:1630-1933) and
+// dispatch.h (dh:38-73): unsupported dtypes / head dims are REJECTED with an error instead of the
+// reference's silent no-op default branch (dh:50-52), nothing synchronises the device (cf. cu:1745,
+// cu:1889) and every launch goes to the caller's stream (cf. the default-stream launches cu:1720).
+#include "../../include/fcsa.h"
+#include "fcsa_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+constexpr float kLog2e = 1.4426950408889634f;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int elem_size(int dtype) { return dtype == FCSA_F32 ? 4 : 2; }
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+bool dim_ok(int d) { return d == 16 || d == 32 || d == 64 || d == 96 || d == 128; }   // cu:84 allowed_dim_heads
+
+int check_problem(const fcsa_problem& p) {
+  if (p.dtype != FCSA_F16 && p.dtype != FCSA_BF16 && p.dtype != FCSA_F32)
+    return fail(FCSA_ERR_UNSUPPORTED, "unsupported dtype %d (expected f32=0, f16=1, bf16=2)", p.dtype);
+  if (p.dtype == FCSA_F32)
+    return fail(FCSA_ERR_UNSUPPORTED, "float32 kernels are not built in this version of libfcsa_hip (f16/bf16 only)");
+  if (!dim_ok(p.dim_head))
+    return fail(FCSA_ERR_UNSUPPORTED, "dim_head %d not in {16, 32, 64, 96, 128}", p.dim_head);
+  if (p.batch < 0 || p.heads < 0 || p.q_len < 0 || p.k_len < 0)
+    return fail(FCSA_ERR_INVALID_ARG, "negative size (B=%d H=%d N=%d M=%d)", p.batch, p.heads, p.q_len, p.k_len);
+  if (p.kv_heads != p.heads && p.kv_heads != 1)
+    return fail(FCSA_ERR_INVALID_ARG, "kv_heads must be heads (%d) or 1, got %d", p.heads, p.kv_heads);
+  if (p.l2norm_qk) {
+    if (p.groups < 1 || p.dim_head % p.groups != 0)
+      return fail(FCSA_ERR_INVALID_ARG, "groups (%d) must divide dim_head (%d)", p.groups, p.dim_head);
+  } else if (p.groups != 1) {
+    return fail(FCSA_ERR_INVALID_ARG, "groups must be 1 when l2norm_qk is 0");
+  }
+  if (!(p.scale == p.scale)) return fail(FCSA_ERR_INVALID_ARG, "scale is NaN");
+  return FCSA_OK;
+}
+
+int check_tensor(const char* name, const fcsa_tensor& t, int es, bool required) {
+  if (t.ptr == nullptr) return required ? fail(FCSA_ERR_INVALID_ARG, "%s: null pointer", name) : FCSA_OK;
+  if ((reinterpret_cast<uintptr_t>(t.ptr) & 15) != 0) return fail(FCSA_ERR_INVALID_ARG, "%s: base not 16-byte aligned", name);
+  const int64_t m = 16 / es;
+  if (t.stride0 % m || t.stride1 % m || t.stride2 % m)
+    return fail(FCSA_ERR_INVALID_ARG, "%s: strides (%lld, %lld, %lld) must keep rows 16-byte aligned", name,
+                (long long)t.stride0, (long long)t.stride1, (long long)t.stride2);
+  return FCSA_OK;
+}
+
+fcsa::View view(const fcsa_tensor& t, int es, bool zero_head_stride = false) {
+  fcsa::View v;
+  v.p = static_cast<char*>(t.ptr);
+  v.sb = t.stride0 * es;
+  v.sh = zero_head_stride ? 0 : t.stride1 * es;
+  v.sn = t.stride2 * es;
+  return v;
+}
+
+fcsa::View contiguous_view(void* p, int64_t heads, int64_t len, int64_t d, int es, bool zero_head_stride = false) {
+  fcsa::View v;
+  v.p = static_cast<char*>(p);
+  v.sb = heads * len * d * es;
+  v.sh = zero_head_stride ? 0 : len * d * es;
+  v.sn = d * es;
+  return v;
+}
+
+// exponent shift (in natural-log units).  The reference always uses `scale` (cu:1216), which bounds the
+// exponent by 0 for groups == 1.  With groups = g the logit reaches scale*g; in f16 the un-normalised
+// P~ = exp(s - shift) must stay below 65504 ~ e^11, so the shift is raised just enough.  Any shift
+// gives the same O; only the saved inv_l carries it, and forward/backward derive it identically.
+float exponent_shift(const fcsa_problem& p) {
+  float shift = p.scale;
+  if (p.dtype == FCSA_F16 && p.l2norm_qk && p.groups > 1) {
+    const float lim = p.scale * (float)p.groups - 10.f;
+    if (lim > shift) shift = lim;
+  }
+  return shift;
+}
+
+struct BwdLayout {
+  size_t delta, dq_slab, dk_slab, dv_slab, total;
+  bool need_dq_slab, need_dk_slab, need_dv_slab;
+};
+
+BwdLayout bwd_layout(const fcsa_problem& p) {
+  BwdLayout L;
+  const bool single = p.kv_heads == 1 && p.heads > 1;
+  const size_t qn = (size_t)p.batch * p.heads * p.q_len;
+  const size_t kn = (size_t)p.batch * p.heads * p.k_len;      // slabs are per q-head
+  L.need_dq_slab = p.l2norm_qk != 0;
+  L.need_dk_slab = p.l2norm_qk != 0 || single;
+  L.need_dv_slab = single;
+  size_t off = 0;
+  L.delta = off;   off = align_up(off + qn * 4, 256);
+  L.dq_slab = off; off = align_up(off + (L.need_dq_slab ? qn * p.dim_head * 4 : 0), 256);
+  L.dk_slab = off; off = align_up(off + (L.need_dk_slab ? kn * p.dim_head * 4 : 0), 256);
+  L.dv_slab = off; off = align_up(off + (L.need_dv_slab ? kn * p.dim_head * 4 : 0), 256);
+  L.total = off;
+  return L;
+}
+
+int launch_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) return fail(FCSA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return FCSA_OK;
+}
+
+// ---- optional per-kernel timing (fcsa_profile_*) -------------------------------------------------
+struct TimedLaunch { const char* name; hipEvent_t start, stop; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<TimedLaunch> g_prof;
+
+// run one kernel launch, bracketed by events on ITS stream when profiling is enabled
+template <typename F> int timed(const char* name, const char* what, hipStream_t s, F&& launch) {
+  bool on;
+  { std::lock_guard<std::mutex> g(g_prof_mu); on = g_prof_on; }
+  if (!on) return launch_check(launch(), what);
+  TimedLaunch t{name, nullptr, nullptr};
+  if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess)
+    return fail(FCSA_ERR_LAUNCH, "%s: hipEventCreate failed", what);
+  (void)hipEventRecord(t.start, s);
+  const hipError_t e = launch();
+  (void)hipEventRecord(t.stop, s);
+  { std::lock_guard<std::mutex> g(g_prof_mu); g_prof.push_back(t); }
+  return launch_check(e, what);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fcsa_last_error(void) { return g_err.c_str(); }
+
+int fcsa_profile_enable(int32_t enable) {
+  std::lock_guard<std::mutex> g(g_prof_mu);
+  g_prof_on = enable != 0;
+  return FCSA_OK;
+}
+
+int fcsa_profile_collect(fcsa_kernel_stat* stats, int32_t capacity) {
+  std::vector<TimedLaunch> rec;
+  { std::lock_guard<std::mutex> g(g_prof_mu); rec.swap(g_prof); }
+  std::vector<fcsa_kernel_stat> agg;
+  for (TimedLaunch& t : rec) {
+    float ms = 0.f;
+    const bool ok = hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess;
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+    if (!ok) continue;
+    fcsa_kernel_stat* st = nullptr;
+    for (auto& a : agg) if (strcmp(a.name, t.name) == 0) st = &a;
+    if (st == nullptr) {
+      fcsa_kernel_stat n;
+      memset(&n, 0, sizeof(n));
+      strncpy(n.name, t.name, sizeof(n.name) - 1);
+      n.min_ms = ms; n.max_ms = ms;
+      agg.push_back(n);
+      st = &agg.back();
+    }
+    st->calls += 1;
+    st->total_ms += ms;
+    if (ms < st->min_ms) st->min_ms = ms;
+    if (ms > st->max_ms) st->max_ms = ms;
+  }
+  if (stats != nullptr)
+    for (int i = 0; i < (int)agg.size() && i < capacity; ++i) stats[i] = agg[i];
+  return (int)agg.size();
+}
+
+int fcsa_debug(char* buf, size_t buf_bytes) {
+  if (buf != nullptr && buf_bytes > 0) {
+    snprintf(buf, buf_bytes,
+             "libfcsa_hip abi=%d arch=gfx950 dtypes=f16,bf16 dim_head=16,32,64,96,128 "
+             "kernels=l2norm,fwd(32x32x16 mfma, 128x64 tile),bwd_dq(128x64),bwd_dkv(128 keys x 64 rows),finalize",
+             FCSA_ABI_VERSION);
+  }
+  return FCSA_ABI_VERSION;
+}
+
+int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_t dim_head, int32_t groups,
+                const fcsa_tensor* x, void* xn, float* inv_norm, void* stream) {
+  if (dtype != FCSA_F16 && dtype != FCSA_BF16) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dtype %d not supported", dtype);
+  if (x == nullptr || xn == nullptr) return fail(FCSA_ERR_INVALID_ARG, "fcsa_l2norm: null argument");
+  if (dim_head <= 0 || dim_head % 8 != 0) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dim_head %d must be a multiple of 8", dim_head);
+  if (dim_head > 512) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dim_head %d > 512", dim_head);
+  if (groups < 1 || dim_head % groups != 0) return fail(FCSA_ERR_INVALID_ARG, "fcsa_l2norm: groups (%d) must divide dim_head (%d)", groups, dim_head);
+  if (int rc = check_tensor("x", *x, 2, true)) return rc;
+  fcsa::NormParams np;
+  np.x = view(*x, 2);
+  np.xn = static_cast<char*>(xn);
+  np.inv_norm = inv_norm;
+  np.B = batch; np.H = heads; np.L = len; np.D = dim_head; np.G = groups;
+  np.eps = 1e-12f;                                        // F.normalize default (flash_cosine_sim_attention.py:46)
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return timed("l2norm", "l2norm", s, [&] { return fcsa::launch_l2norm(dtype, np, s); });
+}
+
+int fcsa_forward(const fcsa_forward_args* a) {
+  if (a == nullptr) return fail(FCSA_ERR_INVALID_ARG, "null args");
+  const fcsa_problem& p = a->p;
+  if (int rc = check_problem(p)) return rc;
+  if (p.causal && a->mask != nullptr) return fail(FCSA_ERR_INVALID_ARG, "mask should not be given if causal (cu:1675)");
+  const int es = elem_size(p.dtype);
+  if (int rc = check_tensor("q", a->q, es, true)) return rc;
+  if (int rc = check_tensor("k", a->k, es, true)) return rc;
+  if (int rc = check_tensor("v", a->v, es, true)) return rc;
+  if (int rc = check_tensor("o", a->o, es, true)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(a->stream);
+  const bool single = p.kv_heads == 1 && p.heads > 1;
+
+  fcsa::FwdParams fp;
+  fp.q = view(a->q, es);
+  fp.k = view(a->k, es, single);
+  fp.v = view(a->v, es, single);
+  fp.o = view(a->o, es);
+  if (p.l2norm_qk) {
+    const fcsa_norm_state& n = a->norm;
+    if (n.qn == nullptr || n.kn == nullptr)
+      return fail(FCSA_ERR_INVALID_ARG, "l2norm_qk needs norm.qn and norm.kn buffers");
+    fcsa::NormParams np;
+    np.eps = 1e-12f;
+    np.D = p.dim_head; np.G = p.groups;
+    np.x = fp.q; np.xn = static_cast<char*>(n.qn); np.inv_norm = n.rq;
+    np.B = p.batch; np.H = p.heads; np.L = p.q_len;
+    if (int rc = timed("l2norm", "l2norm(q)", s, [&] { return fcsa::launch_l2norm(p.dtype, np, s); })) return rc;
+    np.x = view(a->k, es); np.xn = static_cast<char*>(n.kn); np.inv_norm = n.rk;
+    np.B = p.batch; np.H = p.kv_heads; np.L = p.k_len;
+    if (int rc = timed("l2norm", "l2norm(k)", s, [&] { return fcsa::launch_l2norm(p.dtype, np, s); })) return rc;
+    fp.q = contiguous_view(n.qn, p.heads, p.q_len, p.dim_head, es);
+    fp.k = contiguous_view(n.kn, p.kv_heads, p.k_len, p.dim_head, es, single);
+  }
+  fp.inv_l = a->inv_l;
+  fp.mask = a->mask;
+  fp.bias = static_cast<const char*>(a->attn_bias);
+  fp.B = p.batch; fp.H = p.heads; fp.N = p.q_len; fp.M = p.k_len;
+  fp.causal = p.causal; fp.bias_batch = p.bias_batch_dim;
+  fp.c1 = p.scale * kLog2e;
+  fp.c2 = exponent_shift(p) * kLog2e;
+  fp.bias_c = kLog2e;
+  return timed("fwd", "forward", s, [&] { return fcsa::launch_forward(p.dtype, p.dim_head, fp, s); });
+}
+
+size_t fcsa_backward_workspace_bytes(const fcsa_problem* p) {
+  if (p == nullptr) return 0;
+  return bwd_layout(*p).total;
+}
+
+int fcsa_backward(const fcsa_backward_args* a) {
+  if (a == nullptr) return fail(FCSA_ERR_INVALID_ARG, "null args");
+  const fcsa_problem& p = a->p;
+  if (int rc = check_problem(p)) return rc;
+  if (p.causal && a->mask != nullptr) return fail(FCSA_ERR_INVALID_ARG, "mask should not be given if causal (cu:1675)");
+  const int es = elem_size(p.dtype);
+  if (int rc = check_tensor("d_out", a->d_out, es, true)) return rc;
+  if (int rc = check_tensor("o", a->o, es, true)) return rc;
+  if (int rc = check_tensor("v", a->v, es, true)) return rc;
+  if (int rc = check_tensor("dq", a->dq, es, true)) return rc;
+  if (int rc = check_tensor("dk", a->dk, es, true)) return rc;
+  if (int rc = check_tensor("dv", a->dv, es, true)) return rc;
+  if (!p.l2norm_qk) {
+    if (int rc = check_tensor("q", a->q, es, true)) return rc;
+    if (int rc = check_tensor("k", a->k, es, true)) return rc;
+  } else if (a->norm.qn == nullptr || a->norm.kn == nullptr || a->norm.rq == nullptr || a->norm.rk == nullptr) {
+    return fail(FCSA_ERR_INVALID_ARG, "l2norm_qk backward needs norm.qn, norm.kn, norm.rq, norm.rk from forward");
+  }
+  if (a->inv_l == nullptr) return fail(FCSA_ERR_INVALID_ARG, "inv_l: null pointer");
+  if (a->attn_bias == nullptr && a->d_bias != nullptr) return fail(FCSA_ERR_INVALID_ARG, "d_bias without attn_bias");
+  const BwdLayout L = bwd_layout(p);
+  if (a->workspace == nullptr || a->workspace_bytes < L.total)
+    return fail(FCSA_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", a->workspace_bytes, L.total);
+  if ((reinterpret_cast<uintptr_t>(a->workspace) & 255) != 0) return fail(FCSA_ERR_WORKSPACE, "workspace not 256-byte aligned");
+
+  hipStream_t s = static_cast<hipStream_t>(a->stream);
+  const bool single = p.kv_heads == 1 && p.heads > 1;
+  char* ws = static_cast<char*>(a->workspace);
+
+  fcsa::BwdParams bp;
+  if (p.l2norm_qk) {
+    bp.q = contiguous_view(a->norm.qn, p.heads, p.q_len, p.dim_head, es);
+    bp.k = contiguous_view(a->norm.kn, p.kv_heads, p.k_len, p.dim_head, es, single);
+  } else {
+    bp.q = view(a->q, es);
+    bp.k = view(a->k, es, single);
+  }
+  bp.v = view(a->v, es, single);
+  bp.o = view(a->o, es);
+  bp.d_out = view(a->d_out, es);
+  bp.dq_f32 = L.need_dq_slab;
+  bp.dk_f32 = L.need_dk_slab;
+  bp.dv_f32 = L.need_dv_slab;
+  bp.dq = L.need_dq_slab ? contiguous_view(ws + L.dq_slab, p.heads, p.q_len, p.dim_head, 4) : view(a->dq, es);
+  bp.dk = L.need_dk_slab ? contiguous_view(ws + L.dk_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dk, es);
+  bp.dv = L.need_dv_slab ? contiguous_view(ws + L.dv_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dv, es);
+  bp.inv_l = a->inv_l;
+  bp.delta = reinterpret_cast<float*>(ws + L.delta);
+  bp.mask = a->mask;
+  bp.bias = static_cast<const char*>(a->attn_bias);
+  bp.d_bias = a->d_bias;
+  bp.B = p.batch; bp.H = p.heads; bp.N = p.q_len; bp.M = p.k_len;
+  bp.causal = p.causal; bp.bias_batch = p.bias_batch_dim;
+  bp.c1 = p.scale * kLog2e;
+  bp.c2 = exponent_shift(p) * kLog2e;
+  bp.bias_c = kLog2e;
+  bp.scale = p.scale;
+
+  // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
+  if (int rc = timed("bwd_dq", "backward dq", s, [&] { return fcsa::launch_backward_dq(p.dtype, p.dim_head, bp, s); })) return rc;
+  if (int rc = timed("bwd_dkv", "backward dkv", s, [&] { return fcsa::launch_backward_dkv(p.dtype, p.dim_head, bp, s); })) return rc;
+
+  fcsa::NormBwdParams nb;
+  nb.eps = 1e-12f;
+  nb.D = p.dim_head;
+  nb.B = p.batch;
+  if (L.need_dq_slab) {
+    nb.slab = ws + L.dq_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.heads; nb.L = p.q_len;
+    nb.xn = static_cast<const char*>(a->norm.qn); nb.inv_norm = a->norm.rq; nb.G = p.groups;
+    nb.dx = view(a->dq, es);
+    if (int rc = timed("finalize", "finalize dq", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
+  }
+  if (L.need_dk_slab) {
+    nb.slab = ws + L.dk_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.kv_heads; nb.L = p.k_len;
+    if (p.l2norm_qk) { nb.xn = static_cast<const char*>(a->norm.kn); nb.inv_norm = a->norm.rk; nb.G = p.groups; }
+    else             { nb.xn = nullptr; nb.inv_norm = nullptr; nb.G = 1; }
+    nb.dx = view(a->dk, es);
+    if (int rc = timed("finalize", "finalize dk", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
+  }
+  if (L.need_dv_slab) {
+    nb.slab = ws + L.dv_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.kv_heads; nb.L = p.k_len;
+    nb.xn = nullptr; nb.inv_norm = nullptr; nb.G = 1;
+    nb.dx = view(a->dv, es);
+    if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
+  }
+  return FCSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+// fcsa_fwd.hip -- forward kernel of fused cosine-similarity attention for gfx950 (f16 / bf16).
+//
+// Replaces forward_kernel (reference cu:1072-1247).  Math (cu:1204-1246):
+//     S = scale * Qh Kh^T (+ bias);  P~ = valid ? exp(S - shift) : 0;  l = rowsum(P~);
+//     O = (P~ V) / max(l, 1e-10);    inv_l = 1 / max(l, 1e-10)
+// with NO running max / rescale (logits are bounded because q, k are l2-normalised).
+//
+// Decomposition (one workgroup = NW waves = 32*NW query rows; K/V tiles of BN = 64 keys):
+//   * each wave keeps its 32 query rows' Q fragments in VGPRs for the whole key loop
+//     (the reference re-reads the Q tile from global for every column tile, cu:1185-1189);
+//   * K and V tiles are staged global -> VGPR -> LDS, double buffered, one barrier per tile;
+//   * S^T = K Q^T on v_mfma_f32_32x32x16 (A = K rows via ds_read_b128, B = Q registers), so a
+//     lane owns ONE query (column) and 16 keys (rows) of each 32x32 block;
+//   * exp2 + masking + row-sum stay in registers; P~ is packed to 16 bit in place and becomes the
+//     B operand of O^T = V^T P~^T, whose A operand V^T comes from the row-major LDS V tile through
+//     ds_read_b64_tr_b16 (no P~ round trip through shared memory, cf. cu:1222);
+//   * the row sum is a per-lane f32 accumulation of the UN-rounded P~ plus one lane^32 add.
+#include "fcsa_common.cuh"
+#include "fcsa_kernels.h"
+
+namespace fcsa {
+
+template <typename T, int D, int NW, bool MASKED>
+FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<D>& fa, const u32x4 (&qf)[TileGeom<D>::KS],
+                       f32x16 (&o)[TileGeom<D>::DB], float& l, const FwdParams& p, uint64_t word, int i, int j0,
+                       int diff, const char* bias_row) {
+  typedef TileGeom<D> G;
+  typedef Traits<T> TR;
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
+
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED) {
+      w = (uint32_t)(word >> (32 * jb)) >> (4 * fa.hi);
+      if (p.causal) w &= le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi));
+    }
+    const int jbase = j0 + 32 * jb + 4 * fa.hi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float x = s[r] * p.c1 - p.c2;
+      if (bias_row != nullptr) {
+        const int j = jbase + crow(r, 0);
+        if (j < p.M) {
+          const typename TR::elem bv = reinterpret_cast<const typename TR::elem*>(bias_row)[j];
+          x += (float)bv * p.bias_c;
+        }
+      }
+      float e = fast_exp2(x);
+      if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
+      l += e;
+      s[r] = e;
+    }
+    const u32x4 pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 1);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      o[db] = TR::mfma32(fa.tr_frag(vt, 32 * jb, db), pb0, o[db]);
+      o[db] = TR::mfma32(fa.tr_frag(vt, 32 * jb + 16, db), pb1, o[db]);
+    }
+  }
+}
+
+template <typename T, int D, int NW>
+__global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) fwd_kernel(const FwdParams p) {
+  typedef TileGeom<D> G;
+  typedef Traits<T> TR;
+  constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
+  constexpr int TILE_B = BN * G::ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FragAddr<D> fa;
+  fa.init(lane);
+
+  const int MT = (p.N + BM - 1) / BM;
+  int bh, mt;
+  block_to_work(blockIdx.x, p.B * p.H, MT, bh, mt);
+  if (p.causal) mt = MT - 1 - mt;                 // heaviest (longest key range) row tiles first
+  const int b = bh / p.H, h = bh % p.H;
+  const int m0 = mt * BM;
+  const int mw = m0 + wave * 32;                  // first query row of this wave
+  const int i = mw + (lane & 31);                 // this lane's query row
+  const int diff = p.M - p.N;                     // cu:1097 seq_len_diff
+
+  // key tiles this workgroup needs
+  int last_key = p.M - 1;
+  if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
+  const int nt = last_key < 0 ? 0 : last_key / BN + 1;
+
+  // Q fragments (B operand of S^T = K Q^T): features 16*kk + 8*hi .. +8 of row i
+  u32x4 qf[G::KS];
+  {
+    const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      qf[kk] = z;
+      if (i < p.N) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+    }
+  }
+
+  f32x16 o[G::DB];
+#pragma unroll
+  for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float l = 0.f;
+
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
+  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
+  const char* bias_row = nullptr;
+  if (p.bias != nullptr && i < p.N)
+    bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + i) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
+
+  Stager<D, BN, NT> sk, sv;
+  uint8_t mb = 1;
+  if (nt > 0) {
+    sk.load(kbase, p.k.sn, p.M, tid);
+    sv.load(vbase, p.v.sn, p.M, tid);
+    if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
+    sk.store(smem, tid);
+    sv.store(smem + TILE_B, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * BN;
+    const char* kcur = smem + (t & 1) * 2 * TILE_B;
+    const char* vcur = kcur + TILE_B;
+    char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+    const bool more = t + 1 < nt;
+    if (more) {   // issue next tile's global loads now; they land while this tile is computed
+      sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
+      sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
+    }
+    const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);   // valid keys of this tile
+    if (mrow && more) {
+      const int key = j0 + BN + lane;
+      mb = key < p.M ? mrow[key] : (uint8_t)0;
+    }
+    const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
+    const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
+    if (!skip) {
+      if (masked) fwd_tile<T, D, NW, true>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
+      else        fwd_tile<T, D, NW, false>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
+    }
+    if (more) {
+      sk.store(knxt, tid);
+      sv.store(knxt + TILE_B, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
+  const float lt = xhalf_sum(l);
+  const float inv = 1.f / fmaxf(lt, 1e-10f);      // cu:1239 (constants::eps, cu:83)
+  if (i < p.N) {
+    if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = inv;
+    char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = 32 * db + 8 * rq + 4 * fa.hi;
+        if (32 * db + 8 * rq < D) {     // compile-time after unrolling (D % 8 == 0)
+          u32x2 v;
+          v[0] = TR::pack2(o[db][4 * rq] * inv, o[db][4 * rq + 1] * inv);
+          v[1] = TR::pack2(o[db][4 * rq + 2] * inv, o[db][4 * rq + 3] * inv);
+          *reinterpret_cast<u32x2*>(orow + d0 * 2) = v;
+        }
+      }
+  }
+}
+
+template <typename T, int D>
+static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
+  constexpr int NW = 4;
+  constexpr int BM = 32 * NW;
+  const int MT = (p.N + BM - 1) / BM;
+  const size_t lds = 4 * 64 * TileGeom<D>::ROWB;
+  auto kern = fwd_kernel<T, D, NW>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * MT)), dim3(NW * 64), lds, s, p);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_fwd_d(int D, const FwdParams& p, hipStream_t s) {
+  switch (D) {
+    case 16:  return launch_fwd_t<T, 16>(p, s);
+    case 32:  return launch_fwd_t<T, 32>(p, s);
+    case 64:  return launch_fwd_t<T, 64>(p, s);
+    case 96:  return launch_fwd_t<T, 96>(p, s);
+    case 128: return launch_fwd_t<T, 128>(p, s);
+    default:  return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s) {
+  if (p.B * p.H == 0 || p.N == 0) return hipSuccess;
+  if (dtype == 2) return launch_fwd_d<BF16>(D, p, s);
+  if (dtype == 1) return launch_fwd_d<F16>(D, p, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fcsa

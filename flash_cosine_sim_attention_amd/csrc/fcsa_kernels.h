@@ -1,0 +1,68 @@
+// fcsa_kernels.h -- host-side launch interface between the C ABI (fcsa_capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fcsa {
+
+// [B, H, L, D] view with BYTE strides; feature dim contiguous.
+struct View {
+  char*   p;
+  int64_t sb, sh, sn;
+};
+
+struct FwdParams {
+  View q, k, v, o;          // q,k: already normalised (or raw when !l2norm)
+  float* inv_l;             // [B,H,N] or nullptr
+  const uint8_t* mask;      // [B,M] or nullptr
+  const char* bias;         // [Hb,N,M] contiguous, element type = dtype, or nullptr
+  int B, H, N, M;
+  int causal, bias_batch;
+  float c1;                 // scale * log2(e)
+  float c2;                 // shift * log2(e)      (P~ = exp2(c1 * qk - c2))
+  float bias_c;             // log2(e)              (bias enters as bias * log2e)
+};
+
+struct BwdParams {
+  View q, k, v, o, d_out;   // q,k normalised
+  View dq;                  // [B,H,N,D]  dtype, or f32 slab when dq_f32
+  View dk, dv;              // [B,H,M,D]  (per q-head!) dtype or f32 slabs
+  int dq_f32, dk_f32, dv_f32;   // element type of the gradient outputs above: 1 = float32
+  const float* inv_l;       // [B,H,N]
+  float* delta;             // [B,H,N] scratch: written by the dq kernel, read by the dkv kernel
+  const uint8_t* mask;
+  const char* bias;
+  float* d_bias;            // [Hb,N,M] f32 zero-initialised or nullptr
+  int B, H, N, M;
+  int causal, bias_batch;
+  float c1, c2, bias_c;
+  float scale;
+};
+
+struct NormParams {         // grouped l2norm forward:  x -> xn, inv_norm
+  View x;                   // [B,H,L,D]
+  char* xn;                 // contiguous [B,H,L,D]
+  float* inv_norm;          // contiguous [B,H,L,G] or nullptr
+  int B, H, L, D, G;
+  float eps;
+};
+
+struct NormBwdParams {      // dx = reduce_heads(slab) then (optionally) l2norm backward
+  const char* slab;         // [B,HS,L,D] contiguous; element type f32 (slab_f32) or dtype
+  int slab_f32;
+  int HS;                   // heads in the slab (summed down to HO when HS != HO)
+  const char* xn;           // contiguous [B,HO,L,D] normalised input (dtype) or nullptr (no norm)
+  const float* inv_norm;    // [B,HO,L,G]
+  View dx;                  // [B,HO,L,D] out (dtype)
+  int B, HO, L, D, G;
+  float eps;
+};
+
+// dtype: 1 = f16, 2 = bf16 (fcsa_dtype); returns hipError_t of the launch
+hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
+hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s);
+hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t s);
+hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s);
+hipError_t launch_l2norm_bwd(int dtype, const NormBwdParams& p, hipStream_t s);
+
+}  // namespace fcsa

@@ -1,0 +1,247 @@
+// fcsa_norm.hip -- HBM-bound row kernels around the attention kernels (gfx950):
+//
+//   l2norm_kernel      x -> x / max(||x_group||, eps), inv_norm      (reference: l2norm_tensors /
+//                      grouped_l2norm / F.normalize, flash_cosine_sim_attention.py:44-65; in the
+//                      reference these are separate eager PyTorch passes outside the extension)
+//   l2norm_bwd_kernel  dx = l2norm_backward(sum_over_heads(slab))    (reference: torch.autograd through
+//                      F.normalize, plus the f32->dtype casts at cu:1904-1914 and, for single-headed
+//                      K/V, the head reduction the reference does with f32 atomics, cu:1613-1619)
+//
+// Both stream rows with 16-byte loads/stores: D/8 lanes per row, so a wave covers 64/(D/8) rows and
+// one load instruction moves 1 KiB per wave (guide G13).  The group reductions are lane shuffles.
+// A per-(row, group) scalar path handles group sizes that are not a multiple of 8.
+#include "fcsa_common.cuh"
+#include "fcsa_kernels.h"
+
+namespace fcsa {
+
+template <typename T> FCSA_DEV void unpack8(const u32x4& u, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = Traits<T>::lo(u[e]); f[2 * e + 1] = Traits<T>::hi(u[e]); }
+}
+template <typename T> FCSA_DEV u32x4 pack8f(const float (&f)[8]) {
+  u32x4 u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) u[e] = Traits<T>::pack2(f[2 * e], f[2 * e + 1]);
+  return u;
+}
+
+// sum `v` over the LPG consecutive lanes [base, base + LPG) this lane belongs to
+FCSA_DEV float group_sum(float v, int lpg, int pos_in_group, int lane) {
+  if ((lpg & (lpg - 1)) == 0) {
+    for (int o = 1; o < lpg; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
+  const int base = lane - pos_in_group;
+  float s = 0.f;
+  for (int t = 0; t < lpg; ++t) s += __shfl(v, base + t, 64);
+  return s;
+}
+
+struct RowMap {
+  int tpr, rpw, lane, c;
+  int64_t row;
+  bool active;
+  FCSA_DEV void init(int D, int64_t nrows) {
+    tpr = D >> 3;
+    rpw = 64 / tpr;
+    lane = threadIdx.x & 63;
+    const int r = lane / tpr;
+    c = lane - r * tpr;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    row = wave * rpw + r;
+    active = r < rpw && row < nrows;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward, group size multiple of 8
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) {
+  RowMap m;
+  const int64_t nrows = (int64_t)p.B * p.H * p.L;
+  m.init(p.D, nrows);
+  const int dg = p.D / p.G, lpg = dg >> 3;
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = 0.f;
+  int64_t bh = 0;
+  int l = 0;
+  if (m.active) {
+    bh = m.row / p.L;
+    l = (int)(m.row - bh * p.L);
+    const int b = (int)(bh / p.H), h = (int)(bh - (int64_t)b * p.H);
+    const u32x4 u = *reinterpret_cast<const u32x4*>(p.x.p + (int64_t)b * p.x.sb + (int64_t)h * p.x.sh + (int64_t)l * p.x.sn + m.c * 16);
+    unpack8<T>(u, f);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+  ss = group_sum(ss, lpg, m.c % lpg, m.lane);
+  const float inv = 1.f / fmaxf(sqrtf(ss), p.eps);          // F.normalize: x / max(||x||, eps)
+  if (m.active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= inv;
+    *reinterpret_cast<u32x4*>(p.xn + (m.row * p.D + m.c * 8) * 2) = pack8f<T>(f);
+    if (p.inv_norm != nullptr && (m.c % lpg) == 0) p.inv_norm[m.row * p.G + m.c / lpg] = inv;
+  }
+}
+
+// forward, any group size: one thread per (row, group)
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_generic_kernel(const NormParams p) {
+  typedef typename Traits<T>::elem E;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.H * p.L * p.G;
+  if (idx >= total) return;
+  const int64_t row = idx / p.G;
+  const int g = (int)(idx - row * p.G);
+  const int64_t bh = row / p.L;
+  const int l = (int)(row - bh * p.L);
+  const int b = (int)(bh / p.H), h = (int)(bh - (int64_t)b * p.H);
+  const int dg = p.D / p.G;
+  const E* x = reinterpret_cast<const E*>(p.x.p + (int64_t)b * p.x.sb + (int64_t)h * p.x.sh + (int64_t)l * p.x.sn) + g * dg;
+  E* xn = reinterpret_cast<E*>(p.xn) + row * p.D + g * dg;
+  float ss = 0.f;
+  for (int e = 0; e < dg; ++e) { const float v = (float)x[e]; ss += v * v; }
+  const float inv = 1.f / fmaxf(sqrtf(ss), p.eps);
+  for (int e = 0; e < dg; ++e) xn[e] = (E)((float)x[e] * inv);
+  if (p.inv_norm != nullptr) p.inv_norm[idx] = inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: head reduction (+ l2norm backward), group size multiple of 8 (or no norm)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) {
+  RowMap m;
+  const int64_t nrows = (int64_t)p.B * p.HO * p.L;
+  m.init(p.D, nrows);
+  const bool norm = p.xn != nullptr;
+  const int dg = p.D / p.G, lpg = norm ? (dg >> 3) : 1;
+  float g[8], xh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { g[e] = 0.f; xh[e] = 0.f; }
+  int b = 0, h = 0, l = 0;
+  if (m.active) {
+    const int64_t bh = m.row / p.L;
+    l = (int)(m.row - bh * p.L);
+    b = (int)(bh / p.HO);
+    h = (int)(bh - (int64_t)b * p.HO);
+    const int nsum = (p.HS == p.HO) ? 1 : p.HS;
+    for (int hs = 0; hs < nsum; ++hs) {
+      const int64_t srow = ((int64_t)b * p.HS + (p.HS == p.HO ? h : hs)) * p.L + l;
+      if (p.slab_f32) {
+        const f32x4* s = reinterpret_cast<const f32x4*>(p.slab + (srow * p.D + m.c * 8) * 4);
+        const f32x4 a = s[0], c = s[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] += a[e]; g[4 + e] += c[e]; }
+      } else {
+        float t[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(p.slab + (srow * p.D + m.c * 8) * 2), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += t[e];
+      }
+    }
+    if (norm) unpack8<T>(*reinterpret_cast<const u32x4*>(p.xn + (m.row * p.D + m.c * 8) * 2), xh);
+  }
+  if (norm) {
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot += g[e] * xh[e];
+    dot = group_sum(dot, lpg, m.c % lpg, m.lane);
+    if (m.active) {
+      const float r = p.inv_norm[m.row * p.G + m.c / lpg];
+      const bool clamped = r >= 1.f / p.eps;                  // ||x|| <= eps: the clamp has zero slope
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = clamped ? g[e] * r : r * (g[e] - xh[e] * dot);
+    }
+  }
+  if (m.active)
+    *reinterpret_cast<u32x4*>(p.dx.p + (int64_t)b * p.dx.sb + (int64_t)h * p.dx.sh + (int64_t)l * p.dx.sn + m.c * 16) = pack8f<T>(g);
+}
+
+// finalize, any group size: one thread per (row, group)
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_generic_kernel(const NormBwdParams p) {
+  typedef typename Traits<T>::elem E;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.HO * p.L * p.G;
+  if (idx >= total) return;
+  const int64_t row = idx / p.G;
+  const int gi = (int)(idx - row * p.G);
+  const int64_t bh = row / p.L;
+  const int l = (int)(row - bh * p.L);
+  const int b = (int)(bh / p.HO), h = (int)(bh - (int64_t)b * p.HO);
+  const int dg = p.D / p.G;
+  const int nsum = (p.HS == p.HO) ? 1 : p.HS;
+  const E* xn = p.xn ? reinterpret_cast<const E*>(p.xn) + row * p.D + gi * dg : nullptr;
+  E* dx = reinterpret_cast<E*>(p.dx.p + (int64_t)b * p.dx.sb + (int64_t)h * p.dx.sh + (int64_t)l * p.dx.sn) + gi * dg;
+  auto grad = [&](int e) {
+    float s = 0.f;
+    for (int hs = 0; hs < nsum; ++hs) {
+      const int64_t srow = ((int64_t)b * p.HS + (p.HS == p.HO ? h : hs)) * p.L + l;
+      const int64_t o = srow * p.D + gi * dg + e;
+      s += p.slab_f32 ? reinterpret_cast<const float*>(p.slab)[o] : (float)reinterpret_cast<const E*>(p.slab)[o];
+    }
+    return s;
+  };
+  if (xn == nullptr) {
+    for (int e = 0; e < dg; ++e) dx[e] = (E)grad(e);
+    return;
+  }
+  float dot = 0.f;
+  for (int e = 0; e < dg; ++e) dot += grad(e) * (float)xn[e];
+  const float r = p.inv_norm[idx];
+  const bool clamped = r >= 1.f / p.eps;
+  for (int e = 0; e < dg; ++e) {
+    const float ge = grad(e);
+    dx[e] = (E)(clamped ? ge * r : r * (ge - (float)xn[e] * dot));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t launch_l2norm_t(const NormParams& p, hipStream_t s) {
+  const int64_t nrows = (int64_t)p.B * p.H * p.L;
+  if (nrows == 0) return hipSuccess;
+  const int dg = p.D / p.G;
+  if (dg % 8 == 0) {
+    const int rows_per_block = 4 * (64 / (p.D / 8));
+    hipLaunchKernelGGL(l2norm_kernel<T>, dim3((unsigned)((nrows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, p);
+  } else {
+    const int64_t total = nrows * p.G;
+    hipLaunchKernelGGL(l2norm_generic_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_l2norm_bwd_t(const NormBwdParams& p, hipStream_t s) {
+  const int64_t nrows = (int64_t)p.B * p.HO * p.L;
+  if (nrows == 0) return hipSuccess;
+  const int dg = p.D / p.G;
+  if (p.xn == nullptr || dg % 8 == 0) {
+    const int rows_per_block = 4 * (64 / (p.D / 8));
+    hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3((unsigned)((nrows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, p);
+  } else {
+    const int64_t total = nrows * p.G;
+    hipLaunchKernelGGL(l2norm_bwd_generic_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s) {
+  if (dtype == 2) return launch_l2norm_t<BF16>(p, s);
+  if (dtype == 1) return launch_l2norm_t<F16>(p, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_l2norm_bwd(int dtype, const NormBwdParams& p, hipStream_t s) {
+  if (dtype == 2) return launch_l2norm_bwd_t<BF16>(p, s);
+  if (dtype == 1) return launch_l2norm_bwd_t<F16>(p, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fcsa

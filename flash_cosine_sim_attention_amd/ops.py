@@ -1,0 +1,127 @@
+"""Public operator API -- same names, keywords and defaults as the reference package
+(flash_cosine_sim_attention/__init__.py:1, flash_cosine_sim_attention.py:308-334).
+
+Differences from the reference, all inside the boundary:
+  * the (grouped) l2norm of q and k is FUSED into the op (library row kernel + saved inverse
+    norms) instead of two eager F.normalize passes outside the autograd.Function
+    (flash_cosine_sim_attention.py:320-321), so `FlashCosineSimAttention.backward` returns
+    gradients w.r.t. the RAW q, k;
+  * GPU tensors only run on the hand-written gfx950 kernels; there is no silent fallback.
+    CPU tensors are rejected here (the reference routes them to its forward-only tiled
+    PyTorch loop, flash_cosine_sim_attention.py:130-241; that loop is restated as the
+    test oracle in oracle/, not shipped as a product path).
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+import torch.nn.functional as F
+from torch import einsum
+from torch.autograd import Function
+
+from . import _core
+
+
+def exists(val):
+    return val is not None
+
+
+# ---------------------------------------------------------------------------------------------
+# l2norm helpers (flash_cosine_sim_attention.py:38-65)
+# ---------------------------------------------------------------------------------------------
+
+def l2norm(t):
+    return F.normalize(t, dim=-1)
+
+
+def grouped_l2norm(t, groups=1):
+    shape = t.shape
+    dim = shape[-1]
+    t = t.reshape(*shape[:-1], groups, dim // groups)
+    t = l2norm(t)
+    return t.reshape(shape)
+
+
+def l2norm_tensors(*tensors, groups=1):
+    """Differentiable grouped l2norm of each tensor, cast back to the first tensor's dtype
+    (flash_cosine_sim_attention.py:57-65).  Public export of the reference package."""
+    assert len(tensors) > 0
+    dtype = tensors[0].dtype
+    fn = partial(grouped_l2norm, groups=groups)
+    tensors = tuple(map(fn, tensors))
+    tensors = tuple(map(lambda t: t.type(dtype), tensors))
+    return tensors
+
+
+# ---------------------------------------------------------------------------------------------
+# plain O(N*M) attention in PyTorch ops (flash_cosine_sim_attention.py:75-126): public export,
+# runs on whatever device the inputs live on.  Not used by the fused op.
+# ---------------------------------------------------------------------------------------------
+
+def plain_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
+                               l2norm_qk=True, attn_bias_batch_dim=False):
+    assert not (causal and exists(mask)), 'mask should not be supplied if causality is needed'
+    merged = q.ndim == 3
+    single_head_kv = k.ndim == 3
+    if merged:
+        assert k.ndim == 3 and v.ndim == 3, \
+            'if batch and heads are merged for queries, keys and values must also similarly have only 3 dimensions'
+        attn_bias_batch_dim = True
+        q = q[:, None, ...]
+    if l2norm_qk:
+        q, k = l2norm_tensors(q, k, groups=groups)
+    kv_eq = 'b j d' if single_head_kv else 'b h j d'
+    sim = einsum(f'b h i d, {kv_eq} -> b h i j', q, k) * scale
+    if exists(attn_bias):
+        sim = sim + attn_bias.unsqueeze(1 if attn_bias_batch_dim else 0)
+    mask_value = -torch.finfo(sim.dtype).max
+    if causal:
+        i, j = sim.shape[-2:]
+        causal_mask = torch.ones((i, j), device=q.device, dtype=torch.bool).triu(j - i + 1)
+        sim = sim.masked_fill(causal_mask, mask_value)
+    if exists(mask):
+        sim = sim.masked_fill(~mask[:, None, None, :], mask_value)
+    attn = sim.softmax(dim=-1)
+    out = einsum(f'b h i j, {kv_eq} -> b h i d', attn, v)
+    return out.squeeze(1) if merged else out
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd.Function (flash_cosine_sim_attention.py:245-304) with the l2norm fused in
+# ---------------------------------------------------------------------------------------------
+
+class FlashCosineSimAttention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, attn_bias, scale, groups, causal, l2norm_qk, attn_bias_batch_dim):
+        should_backwards = any(exists(t) and t.requires_grad for t in (q, k, v, attn_bias))     # cu:1689
+        o, saved = _core.attention_forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal,
+                                           l2norm_qk=l2norm_qk, groups=groups, need_backward=should_backwards)
+        ctx.should_backwards = should_backwards
+        if not should_backwards:
+            return o
+        ctx.saved = saved
+        ctx.shapes = (q.shape, k.shape, v.shape)
+        ctx.bias_grad = exists(attn_bias) and attn_bias.requires_grad
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        assert ctx.should_backwards
+        q_shape, k_shape, v_shape = ctx.shapes
+        dq, dk, dv, db = _core.attention_backward(do, ctx.saved, q_shape, k_shape, v_shape, ctx.bias_grad)
+        return dq, dk, dv, None, db, None, None, None, None, None
+
+
+flash_cosine_sim_attention_hip = FlashCosineSimAttention.apply
+
+
+def flash_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
+                               l2norm_qk=True, attn_bias_batch_dim=False):
+    """Fused cosine-similarity attention; signature of flash_cosine_sim_attention.py:308-319."""
+    if not q.is_cuda:
+        raise RuntimeError(
+            'flash_cosine_sim_attention_amd runs on MI355X GPU tensors only (hand-written HIP kernels, '
+            'no CPU fallback); use plain_cosine_sim_attention for CPU tensors')
+    return flash_cosine_sim_attention_hip(q, k, v, mask, attn_bias, scale, groups, causal, l2norm_qk,
+                                          attn_bias_batch_dim)

@@ -1,0 +1,167 @@
+/*
+ * fcsa.h -- C ABI of the MI355X (gfx950) fused cosine-similarity attention library
+ *           (libfcsa_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of lucidrains/flash-cosine-sim-attention:
+ * it exports what the reference's native extension exports through pybind
+ *   forward  (flash_cosine_sim_attention_cuda.cu:1630-1748, bound at cu:1928-1933)
+ *   backward (flash_cosine_sim_attention_cuda.cu:1752-1917)
+ *   debug    (cu:1928-1933)
+ * as plain `extern "C"` functions over raw device pointers, element strides and sizes.
+ * No torch / ATen types cross this boundary.  The caller owns every buffer (inputs,
+ * outputs, saved state, workspace) and passes the HIP stream to launch on; the library
+ * never allocates, never synchronises the device and never touches the default stream
+ * unless `stream` is NULL (reference: default stream + cudaDeviceSynchronize after every
+ * call, cu:1720, cu:1745, cu:1889).
+ *
+ * Layout conventions
+ *   q, o, d_out, dq        : [B, H, N, D]          (reference accessor order, cu:30-35)
+ *   k, v, dk, dv           : [B, Hk, M, D], Hk == H, or Hk == 1 for single-headed key/values
+ *                            (reference: 3-D k/v unsqueezed at cu:1656-1660, is_single_head_kv cu:1679)
+ *   mask                   : [B, M] bytes, non-zero = keep   (cu:1208-1211; torch.bool storage)
+ *   attn_bias              : [Hb, N, M], Hb == H (per head) or Hb == B when bias_batch_dim (cu:1168, cu:1214)
+ *   inv_l                  : [B, H, N] float32 = 1 / max(rowsum, 1e-10)   (cu:1236-1242)
+ *   Tensors are described by a base pointer and ELEMENT strides for the three leading
+ *   dims; the feature dim must be contiguous (stride 1) and every row 16-byte aligned.
+ *   A merged batch-heads query ([BH, N, D], cu:1647-1654) is passed as B = BH, H = 1.
+ *
+ * Errors: every entry point returns FCSA_OK (0) or a negative code and records a message
+ * retrievable with fcsa_last_error() (thread local).  Unsupported dtypes / head dims are
+ * rejected (the reference silently does nothing: dispatch.h:50-52).
+ */
+#ifndef FCSA_H_
+#define FCSA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCSA_ABI_VERSION 1
+
+enum fcsa_status {
+  FCSA_OK = 0,
+  FCSA_ERR_INVALID_ARG = -1,   /* bad shape / stride / null pointer / mask together with causal (cu:1675) */
+  FCSA_ERR_UNSUPPORTED = -2,   /* dtype or head dim outside {f32,f16,bf16} x {16,32,64,96,128} (cu:1702-1703) */
+  FCSA_ERR_LAUNCH = -3,        /* hipGetLastError() after a launch */
+  FCSA_ERR_WORKSPACE = -4      /* workspace too small */
+};
+
+enum fcsa_dtype {
+  FCSA_F32 = 0,
+  FCSA_F16 = 1,
+  FCSA_BF16 = 2
+};
+
+/* A [d0, d1, d2, D] tensor view: element strides of the leading dims, last dim contiguous. */
+typedef struct fcsa_tensor {
+  void*   ptr;
+  int64_t stride0;   /* batch */
+  int64_t stride1;   /* head  (0 allowed: broadcast over heads, e.g. single-head kv) */
+  int64_t stride2;   /* sequence position */
+} fcsa_tensor;
+
+/* Problem description shared by forward and backward (reference: the scalar arguments of
+ * forward_kernel / backward_kernel, cu:1072-1088, cu:1339-1360). */
+typedef struct fcsa_problem {
+  int32_t dtype;            /* fcsa_dtype of q,k,v,o,grads,bias */
+  int32_t batch;            /* B */
+  int32_t heads;            /* H */
+  int32_t kv_heads;         /* H or 1 */
+  int32_t q_len;            /* N */
+  int32_t k_len;            /* M */
+  int32_t dim_head;         /* D in {16,32,64,96,128} (cu:84) */
+  int32_t causal;           /* cu:1210: key j valid for query i iff j - (M - N) <= i */
+  int32_t bias_batch_dim;   /* attn_bias leading dim is batch (1) or heads (0) (cu:1474) */
+  int32_t l2norm_qk;        /* 1: q,k are RAW and the library normalises them (fused form of
+                               flash_cosine_sim_attention.py:320-321); 0: q,k used as given
+                               (exactly the reference extension's contract) */
+  int32_t groups;           /* l2norm groups (flash_cosine_sim_attention.py:50-55); 1 if !l2norm_qk */
+  float   scale;            /* logits = scale * qh.kh ; exponent shift = -scale (cu:1216) */
+} fcsa_problem;
+
+/* State the fused-l2norm forward saves for backward (all caller-allocated, contiguous):
+ *   qn [B,H,N,D], kn [B,Hk,M,D] in `dtype`  : normalised q, k (what the reference's autograd
+ *        would have saved as the outputs of F.normalize)
+ *   rq [B,H,N,G], rk [B,Hk,M,G] float32     : 1 / max(||x_group||, 1e-12)
+ * Unused (may be NULL) when l2norm_qk == 0. */
+typedef struct fcsa_norm_state {
+  void*  qn;
+  void*  kn;
+  float* rq;
+  float* rk;
+} fcsa_norm_state;
+
+typedef struct fcsa_forward_args {
+  fcsa_problem    p;
+  fcsa_tensor     q, k, v;       /* inputs (borrowed, never written) */
+  fcsa_tensor     o;             /* output [B,H,N,D] */
+  float*          inv_l;         /* [B,H,N] contiguous, or NULL when no backward will follow
+                                    (reference: need_store_rowsum, cu:1086, cu:1241) */
+  const uint8_t*  mask;          /* [B,M] contiguous or NULL */
+  const void*     attn_bias;     /* [Hb,N,M] contiguous or NULL */
+  fcsa_norm_state norm;
+  void*           stream;        /* hipStream_t */
+} fcsa_forward_args;
+
+typedef struct fcsa_backward_args {
+  fcsa_problem    p;
+  fcsa_tensor     d_out, o;      /* [B,H,N,D] */
+  const float*    inv_l;         /* [B,H,N] from forward */
+  fcsa_tensor     q, k, v;       /* the same tensors forward saw (q,k ignored when l2norm_qk: qn/kn are used) */
+  const uint8_t*  mask;
+  const void*     attn_bias;
+  fcsa_norm_state norm;          /* from forward (l2norm_qk only) */
+  fcsa_tensor     dq;            /* [B,H,N,D]  out */
+  fcsa_tensor     dk, dv;        /* [B,Hk,M,D] out */
+  float*          d_bias;        /* [Hb,N,M] float32, ZERO-INITIALISED by the caller, or NULL
+                                    (reference: f32 atomicAdd target, cu:1574-1576, cast at cu:1912) */
+  void*           workspace;     /* >= fcsa_backward_workspace_bytes(&p) bytes, 256-byte aligned */
+  size_t          workspace_bytes;
+  void*           stream;
+} fcsa_backward_args;
+
+/* Replaces flash_cosine_sim_attention_forward (cu:1630-1748). */
+int fcsa_forward(const fcsa_forward_args* args);
+
+/* Replaces flash_cosine_sim_attention_backward (cu:1752-1917): delta pre-pass (cu:1256-1335)
+ * + gradient kernels (cu:1339-1626) + the casts at cu:1893-1916.  With l2norm_qk it also
+ * applies the l2norm backward that torch.autograd performs in the reference. */
+int fcsa_backward(const fcsa_backward_args* args);
+
+/* Scratch needed by fcsa_backward for this problem (delta, f32 gradient slabs). */
+size_t fcsa_backward_workspace_bytes(const fcsa_problem* p);
+
+/* Standalone grouped l2norm on device: the public l2norm_tensors (flash_cosine_sim_attention.py:57-65).
+ * x [B,H,N,D] (strided) -> xn [B,H,N,D] contiguous, inv_norm [B,H,N,G] float32 (may be NULL). */
+int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_t dim_head, int32_t groups,
+                const fcsa_tensor* x, void* xn, float* inv_norm, void* stream);
+
+/* Replaces the extension's debug() hook (cu:1928-1933): returns the ABI version and, when
+ * `buf` is non-NULL, writes a NUL-terminated description of the compiled kernels into it. */
+int fcsa_debug(char* buf, size_t buf_bytes);
+
+/* Optional per-kernel timing for bench.py's roofline line (not part of the reference's surface).
+ * While enabled, the library records a HIP event pair on the launch stream around every kernel it
+ * launches; fcsa_profile_collect waits for those events, aggregates them per kernel name
+ * ("l2norm", "fwd", "bwd_dq", "bwd_dkv", "finalize"), writes up to `capacity` entries and returns
+ * the number of distinct kernels seen (negative on error).  Collecting resets the record. */
+typedef struct fcsa_kernel_stat {
+  char    name[32];
+  int32_t calls;
+  float   total_ms;
+  float   min_ms;
+  float   max_ms;
+} fcsa_kernel_stat;
+int fcsa_profile_enable(int32_t enable);
+int fcsa_profile_collect(fcsa_kernel_stat* stats, int32_t capacity);
+
+/* Message for the last non-OK status returned on this thread ("" if none). */
+const char* fcsa_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCSA_H_ */

@@ -1,0 +1,166 @@
+"""CPU-only checks of the drop-in boundary: libfcsa_hip.so loads, exports every symbol include/fcsa.h
+declares, its structs have the layout the ctypes binding assumes, and argument validation returns the
+documented error codes WITHOUT touching a GPU (no kernel is launched by any call here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fcsa.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from flash_cosine_sim_attention_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fcsa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_exports_every_declared_symbol(lib):
+    names = _declared_functions()
+    assert {"fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_l2norm", "fcsa_debug",
+            "fcsa_last_error"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fcsa.h but not exported"
+    from flash_cosine_sim_attention_amd import _lib
+    assert set(_lib.EXPORTS) == set(names)
+
+
+def test_struct_layout_matches_c_compiler(tmp_path):
+    """sizeof/offsetof as gcc sees include/fcsa.h == the ctypes mirror in _lib.py."""
+    from flash_cosine_sim_attention_amd import _lib
+    prog = tmp_path / "layout.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "fcsa.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(fcsa_tensor), sizeof(fcsa_problem), sizeof(fcsa_norm_state),
+         sizeof(fcsa_forward_args), sizeof(fcsa_backward_args));
+  printf("%zu %zu %zu %zu\n", offsetof(fcsa_forward_args, o), offsetof(fcsa_forward_args, inv_l),
+         offsetof(fcsa_forward_args, norm), offsetof(fcsa_forward_args, stream));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(fcsa_backward_args, inv_l), offsetof(fcsa_backward_args, q),
+         offsetof(fcsa_backward_args, dq), offsetof(fcsa_backward_args, workspace), offsetof(fcsa_backward_args, stream));
+  printf("%zu %zu\n", offsetof(fcsa_problem, scale), offsetof(fcsa_problem, groups));
+  return 0;
+}''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    sizes = list(map(int, out[0].split()))
+    assert sizes == [C.sizeof(_lib.Tensor), C.sizeof(_lib.Problem), C.sizeof(_lib.NormState),
+                     C.sizeof(_lib.ForwardArgs), C.sizeof(_lib.BackwardArgs)]
+    F, B, P = _lib.ForwardArgs, _lib.BackwardArgs, _lib.Problem
+    assert list(map(int, out[1].split())) == [F.o.offset, F.inv_l.offset, F.norm.offset, F.stream.offset]
+    assert list(map(int, out[2].split())) == [B.inv_l.offset, B.q.offset, B.dq.offset, B.workspace.offset, B.stream.offset]
+    assert list(map(int, out[3].split())) == [P.scale.offset, P.groups.offset]
+
+
+def _problem(**kw):
+    from flash_cosine_sim_attention_amd import _lib
+    d = dict(dtype=_lib.FCSA_BF16, batch=1, heads=2, kv_heads=2, q_len=8, k_len=8, dim_head=64, causal=0,
+             bias_batch_dim=0, l2norm_qk=0, groups=1, scale=8.0)
+    d.update(kw)
+    return _lib.Problem(*[d[f[0]] for f in _lib.Problem._fields_])
+
+
+def _fwd_args(prob, mask=None):
+    from flash_cosine_sim_attention_amd import _lib
+    t = _lib.Tensor(0x1000, 1024, 512, 64)      # fake, never dereferenced: validation fails first
+    return _lib.ForwardArgs(prob, t, t, t, t, None, mask, None, _lib.NormState(None, None, None, None), None)
+
+
+def test_validation_errors_without_gpu(lib):
+    from flash_cosine_sim_attention_amd import _lib
+    UNSUPPORTED, INVALID = -2, -1
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(dim_head=48))))
+    assert rc == UNSUPPORTED and b"dim_head 48" in lib.fcsa_last_error()
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(dtype=7))))
+    assert rc == UNSUPPORTED and b"dtype" in lib.fcsa_last_error()
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(kv_heads=3))))
+    assert rc == INVALID and b"kv_heads" in lib.fcsa_last_error()
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(causal=1), mask=0x2000)))
+    assert rc == INVALID and b"causal" in lib.fcsa_last_error()
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(l2norm_qk=1, groups=5))))
+    assert rc == INVALID and b"groups" in lib.fcsa_last_error()
+    bad = _fwd_args(_problem())
+    bad.q = _lib.Tensor(0x1004, 1024, 512, 64)
+    rc = lib.fcsa_forward(C.byref(bad))
+    assert rc == INVALID and b"aligned" in lib.fcsa_last_error()
+    bad = _fwd_args(_problem())
+    bad.k = _lib.Tensor(None, 0, 0, 0)
+    rc = lib.fcsa_forward(C.byref(bad))
+    assert rc == INVALID and b"k: null" in lib.fcsa_last_error()
+    assert lib.fcsa_forward(None) == INVALID
+    with pytest.raises(RuntimeError, match="status -2"):
+        _lib.check(lib.fcsa_forward(C.byref(_fwd_args(_problem(dim_head=48)))), "fcsa_forward")
+
+
+def test_backward_workspace_formula(lib):
+    # delta [B,H,N] f32 always; f32 slabs: dq when l2norm, dk when l2norm or single-head kv, dv when single-head kv
+    al = lambda x: (x + 255) // 256 * 256
+    B, H, N, M, D = 2, 4, 100, 120, 64
+    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=D)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4)
+    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=D, l2norm_qk=1)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + al(B * H * N * D * 4) + al(B * H * M * D * 4)
+    p = _problem(batch=B, heads=H, kv_heads=1, q_len=N, k_len=M, dim_head=D)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + 2 * al(B * H * M * D * 4)
+
+
+def test_debug_string(lib):
+    buf = C.create_string_buffer(512)
+    assert lib.fcsa_debug(buf, 512) == 1
+    assert b"gfx950" in buf.value and b"bf16" in buf.value
+
+
+def test_host_canonicalisation_rejects_bad_inputs_on_cpu():
+    import torch
+    import flash_cosine_sim_attention_amd as F
+    from flash_cosine_sim_attention_amd import _core
+    q = torch.randn(1, 2, 8, 64)
+    with pytest.raises(RuntimeError, match="GPU"):
+        F.flash_cosine_sim_attention(q, q, q)
+    with pytest.raises(RuntimeError, match="GPU"):
+        _core.attention_forward(q, q, q)
+
+
+def test_public_api_names_and_signature():
+    """Same exported names / keyword defaults as the reference package (__init__.py:1, fcsa.py:308-319)."""
+    import inspect
+    import flash_cosine_sim_attention_amd as F
+    for n in ("flash_cosine_sim_attention", "plain_cosine_sim_attention", "l2norm_tensors", "debug"):
+        assert hasattr(F, n)
+    sig = inspect.signature(F.flash_cosine_sim_attention)
+    assert list(sig.parameters) == ["q", "k", "v", "mask", "attn_bias", "scale", "groups", "causal", "l2norm_qk",
+                                    "attn_bias_batch_dim"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["mask"], d["attn_bias"], d["scale"], d["groups"], d["causal"], d["l2norm_qk"], d["attn_bias_batch_dim"]) == \
+           (None, None, 8, 1, False, True, False)
+    assert list(inspect.signature(F.plain_cosine_sim_attention).parameters) == list(sig.parameters)
+
+
+def test_plain_torch_restatement_matches_oracle_on_cpu():
+    """ops.plain_cosine_sim_attention (public export) against the numpy oracle and a reference fixture."""
+    import numpy as np
+    import cases as Cs
+    import flash_cosine_sim_attention_amd as F
+    from oracle import cosine_sim_oracle as O
+    for name in ("g03_mask_d32_n63_f32", "g04_causal_biasH_d32_n63_f32", "g07_causal_singlekv_d128_n63_f32", "g18_merged_bh_d32_f32"):
+        case = Cs.BY_NAME[name]
+        inp = Cs.make_inputs(case)
+        o = F.plain_cosine_sim_attention(inp["q"], inp["k"], inp["v"], mask=inp["mask"], attn_bias=inp["attn_bias"],
+                                         **Cs.op_kwargs(case))
+        gold = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["o_plain"]
+        assert np.abs(o.numpy() - gold).max() <= 2e-5

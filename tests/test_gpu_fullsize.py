@@ -1,0 +1,148 @@
+"""Full-size checks at BASELINE.json's configs C2-C5 where the float64 oracle is too slow.
+
+Two kinds of evidence:
+  * a plain PyTorch float32 evaluation of the same math on (batch, head) SLICES on the GPU
+    (the floating-point reference the tier allows beside the oracle), and
+  * size-independent identities of the operator:
+      - rows of P sum to 1:      V = 1  =>  O = 1 on every row that has a valid key
+      - linearity in V:          O(a v1 + b v2) = a O(v1) + b O(v2)
+      - key-permutation invariance (non-causal): permuting (k, v, mask) together leaves O unchanged
+      - colsum identity:         sum_j dV[j] = sum_i dO[i]            (rows of P sum to 1)
+      - dS rows sum to 0:        sum_j d_bias[i, j] = 0
+      - l2norm tangent space:    <dq_i, q_i> = 0 and <dk_j, k_j> = 0 per group (gradient of a
+                                 scale-invariant function is orthogonal to its argument)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_slice(q, k, v, mask, causal, scale, groups):
+    """float32 PyTorch evaluation of softmax(scale * qn kn^T) v for [n, d] x [m, d] slices."""
+    q, k, v = q.float(), k.float(), v.float()
+    d = q.shape[-1]
+
+    def nrm(t):
+        tg = t.reshape(t.shape[0], groups, d // groups)
+        return torch.nn.functional.normalize(tg, dim=-1).reshape(t.shape)
+
+    s = (nrm(q) @ nrm(k).t()) * scale
+    n, m = s.shape
+    if causal:
+        s = s.masked_fill(torch.ones(n, m, dtype=torch.bool, device=s.device).triu(m - n + 1), float("-inf"))
+    if mask is not None:
+        s = s.masked_fill(~mask[None, :], float("-inf"))
+    return torch.softmax(s, dim=-1) @ v
+
+
+def _configs():
+    return {
+        "C2": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype=torch.float16, causal=False, mask=False, scale=8, groups=1),
+        "C3": dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.bfloat16, causal=True, mask=False, scale=8, groups=1),
+        "C4": dict(q=(1, 8, 1024, 64), kv=(1, 8, 8192, 64), dtype=torch.float16, causal=False, mask=True, scale=8, groups=1),
+        "C5": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, mask=False, scale=1, groups=8),
+    }
+
+
+def _make(cfg, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(cfg["q"], device="cuda", dtype=cfg["dtype"], generator=g)
+    k = torch.randn(cfg["kv"], device="cuda", dtype=cfg["dtype"], generator=g)
+    v = torch.randn(cfg["kv"], device="cuda", dtype=cfg["dtype"], generator=g)
+    mask = None
+    if cfg["mask"]:
+        mask = torch.rand((cfg["q"][0], cfg["kv"][-2]), device="cuda", generator=g) > 0.25     # benchmark.py:120
+    return q, k, v, mask
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
+def test_forward_fullsize_vs_f32_slices_and_identities(name):
+    import flash_cosine_sim_attention_amd as F
+    cfg = _configs()[name]
+    q, k, v, mask = _make(cfg)
+    kw = dict(mask=mask, causal=cfg["causal"], scale=cfg["scale"], groups=cfg["groups"])
+    o = F.flash_cosine_sim_attention(q, k, v, **kw)
+    assert torch.isfinite(o).all()
+    atol = 2e-3 if cfg["dtype"] == torch.float16 else 1.5e-2
+    single = k.dim() == 3
+    for (b, h) in ((0, 0), (cfg["q"][0] - 1, cfg["q"][1] - 1), (0, 3)):
+        kk, vv = (k[b], v[b]) if single else (k[b, h], v[b, h])
+        ref = _ref_slice(q[b, h], kk, vv, None if mask is None else mask[b], cfg["causal"], cfg["scale"], cfg["groups"])
+        err = (o[b, h].float() - ref).abs().max().item()
+        assert err <= atol, f"{name} slice {(b, h)} max-abs {err:.3e}"
+    # rows of P sum to one
+    ones = torch.ones_like(v)
+    o1 = F.flash_cosine_sim_attention(q, k, ones, **kw)
+    assert (o1.float() - 1).abs().max().item() <= (2e-3 if cfg["dtype"] == torch.float16 else 8e-3)
+    # linearity in V
+    v2 = torch.randn_like(v)
+    o2 = F.flash_cosine_sim_attention(q, k, v2, **kw)
+    o12 = F.flash_cosine_sim_attention(q, k, (v + v2), **kw)
+    assert (o12.float() - (o.float() + o2.float())).abs().max().item() <= 4 * atol
+    if not cfg["causal"]:
+        perm = torch.randperm(k.shape[-2], device="cuda")
+        kp, vp = k.index_select(-2, perm), v.index_select(-2, perm)
+        mp = None if mask is None else mask.index_select(-1, perm)
+        op = F.flash_cosine_sim_attention(q, kp, vp, mask=mp, causal=False, scale=cfg["scale"], groups=cfg["groups"])
+        assert (op.float() - o.float()).abs().max().item() <= 2 * atol
+
+
+@pytest.mark.parametrize("name", ["C3", "C5", "C4"])
+def test_backward_fullsize_identities_and_slices(name):
+    import flash_cosine_sim_attention_amd as F
+    cfg = _configs()[name]
+    q, k, v, mask = _make(cfg, seed=1)
+    q.requires_grad_(); k.requires_grad_(); v.requires_grad_()
+    kw = dict(mask=mask, causal=cfg["causal"], scale=cfg["scale"], groups=cfg["groups"])
+    o = F.flash_cosine_sim_attention(q, k, v, **kw)
+    do = torch.randn_like(o)
+    o.backward(do)
+    dq, dk, dv = q.grad, k.grad, v.grad
+    for g in (dq, dk, dv):
+        assert torch.isfinite(g).all()
+    bf = cfg["dtype"] == torch.bfloat16
+    # colsum identity: sum_j dV[b,h,j,:] == sum_i dO[b,h,i,:]   (summed over heads too for single-head kv)
+    lhs = dv.float().sum(-2)
+    rhs = do.float().sum(-2)
+    if k.dim() == 3:
+        rhs = rhs.sum(1)
+    scale_ref = do.float().abs().sum(-2).max().item()
+    assert (lhs - rhs).abs().max().item() <= (1.5e-2 if bf else 4e-3) * scale_ref
+    # tangent-space identity of the fused l2norm backward
+    G = cfg["groups"]
+    for x, gx in ((q, dq), (k, dk)):
+        xg = x.detach().float().reshape(*x.shape[:-1], G, -1)
+        gg = gx.float().reshape(*x.shape[:-1], G, -1)
+        dot = (xg * gg).sum(-1).abs()
+        mag = (xg.norm(dim=-1) * gg.norm(dim=-1)) + 1e-20
+        assert (dot / mag).max().item() <= (6e-2 if bf else 1.5e-2)
+    # torch autograd float32 on one (b, h) slice (dq only needs that head; dk/dv too when kv has heads)
+    b, h = cfg["q"][0] - 1, 1
+    single = k.dim() == 3
+    qs = q.detach()[b, h].float().requires_grad_()
+    ks = (k.detach()[b] if single else k.detach()[b, h]).float().requires_grad_()
+    vs = (v.detach()[b] if single else v.detach()[b, h]).float().requires_grad_()
+    ref = _ref_slice(qs, ks, vs, None if mask is None else mask[b], cfg["causal"], cfg["scale"], cfg["groups"])
+    (ref * do[b, h].float()).sum().backward()
+    rel = lambda a, r: ((a.float() - r).norm() / r.norm()).item()
+    tol = 1.2e-2 if bf else 3e-3
+    assert rel(dq[b, h], qs.grad) <= tol, rel(dq[b, h], qs.grad)
+    if not single:
+        assert rel(dk[b, h], ks.grad) <= tol, rel(dk[b, h], ks.grad)
+        assert rel(dv[b, h], vs.grad) <= tol, rel(dv[b, h], vs.grad)
+
+
+def test_dbias_rows_sum_to_zero():
+    import flash_cosine_sim_attention_amd as F
+    torch.manual_seed(3)
+    b, h, n, m, d = 2, 4, 300, 420, 64
+    q = torch.randn(b, h, n, d, device="cuda", dtype=torch.float16)
+    k = torch.randn(b, h, m, d, device="cuda", dtype=torch.float16)
+    v = torch.randn(b, h, m, d, device="cuda", dtype=torch.float16)
+    bias = (0.5 * torch.randn(h, n, m, device="cuda", dtype=torch.float16)).requires_grad_()
+    o = F.flash_cosine_sim_attention(q, k, v, attn_bias=bias)
+    o.backward(torch.randn_like(o))
+    rowsum = bias.grad.float().sum(-1).abs().max().item()
+    assert rowsum <= 2e-2 * bias.grad.float().abs().sum(-1).max().item() + 1e-3

@@ -120,3 +120,24 @@ def test_flop_convention():
     assert abs(O.algorithmic_flops(4, 8, 4096, 4096, 64, causal=True) / 1e9 - 240.58) < 0.01
     assert O.causal_valid_count(4, 6) == 3 + 4 + 5 + 6
     assert O.causal_valid_count(3, 2) == 0 + 1 + 2
+
+
+def test_cpu_port_matches_numpy_oracle():
+    """oracle/torch_cpu_port.py (the cpu_baseline leg of bench.py) == the numpy oracle, forward and grads."""
+    import torch
+    from oracle import torch_cpu_port as P
+    torch.manual_seed(0)
+    for single, causal, groups in ((False, True, 1), (True, False, 2)):
+        q = torch.randn(2, 3, 50, 32, dtype=torch.float64, requires_grad=True)
+        kv = (2, 70, 32) if single else (2, 3, 70, 32)
+        k = torch.randn(kv, dtype=torch.float64, requires_grad=True)
+        v = torch.randn(kv, dtype=torch.float64, requires_grad=True)
+        do = torch.randn(2, 3, 50, 32, dtype=torch.float64)
+        o = P.plain_attention_cpu(q, k, v, causal=causal, groups=groups)
+        o.backward(do)
+        n = lambda t: t.detach().numpy()
+        ro = O.plain_attention(n(q), n(k), n(v), causal=causal, groups=groups)
+        rdq, rdk, rdv, _ = O.attention_backward(n(do), n(q), n(k), n(v), causal=causal, groups=groups)
+        assert np.abs(n(o) - ro).max() < 1e-10
+        for a, r in ((q.grad, rdq), (k.grad, rdk), (v.grad, rdv)):
+            assert np.abs(n(a) - r).max() < 1e-9

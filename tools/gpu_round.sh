@@ -1,0 +1,9 @@
+#!/bin/bash
+# One GPU-box session: diagnostics -> parity tests -> bench -> rocprofv3 kernel stats.  Everything lands in gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+echo "== rocminfo =="; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6
+echo "== diag =="; timeout 600 python tools/gpu_diag.py > gpurun_out/diag.log 2>&1; tail -n 70 gpurun_out/diag.log
+echo "== pytest gpu =="; timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -x -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; tail -n 40 gpurun_out/pytest_gpu.log
+echo "== bench =="; timeout 600 python bench.py > gpurun_out/bench.log 2>&1; tail -n 3 gpurun_out/bench.log
