@@ -1,4 +1,4 @@
-// fcsa_bwd.hip -- backward kernels of fused cosine-similarity attention for gfx950 (f16 / bf16).
+// fcsa_bwd.hip -- backward kernels of fused cosine-similarity attention for gfx950 (f16 / bf16 / f32).
 //
 // Replaces backward_preprocess (reference cu:1256-1335) and backward_kernel (cu:1339-1626).
 // Math, with Qh/Kh the normalised inputs:
@@ -25,37 +25,15 @@
 
 namespace fcsa {
 
-template <typename T, int D>
-FCSA_DEV void store_row_tile(char* row, const f32x16 (&acc)[TileGeom<D>::DB], float mul, int hi, bool as_f32) {
-  typedef Traits<T> TR;
-  // lane (row, hi) holds features 32*db + 8*rq + 4*hi + 0..3
-#pragma unroll
-  for (int db = 0; db < TileGeom<D>::DB; ++db)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      if (32 * db + 8 * rq < D) {
-        const int d0 = 32 * db + 8 * rq + 4 * hi;
-        if (as_f32) {
-          f32x4 v = {acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul, acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul};
-          *reinterpret_cast<f32x4*>(row + d0 * 4) = v;
-        } else {
-          u32x2 v;
-          v[0] = TR::pack2(acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul);
-          v[1] = TR::pack2(acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul);
-          *reinterpret_cast<u32x2*>(row + d0 * 2) = v;
-        }
-      }
-    }
-}
-
 // =============================================================================================
 // dQ kernel
 // =============================================================================================
 template <typename T, int D, bool MASKED>
-FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<D>& fa, const u32x4 (&qf)[TileGeom<D>::KS],
-                      const u32x4 (&dof)[TileGeom<D>::KS], f32x16 (&dq)[TileGeom<D>::DB], float lc, float delta,
-                      const BwdParams& p, uint64_t word, int i, int j0, int diff, const char* bias_row, float* dbias_row) {
-  typedef TileGeom<D> G;
+FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
+                      const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
+                      f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
+                      int i, int j0, int diff, const char* bias_row, float* dbias_row) {
+  typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
@@ -87,18 +65,16 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<D>& fa, con
       if (dbias_row != nullptr && j < p.M && ds != 0.f) atomicAdd(dbias_row + j, ds);   // cu:1574-1576
       s[r] = ds;
     }
-    const u32x4 pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 1);
+    SecondB<T> pb;
+    pb.prep(s);
 #pragma unroll
-    for (int db = 0; db < G::DB; ++db) {
-      dq[db] = TR::mfma32(fa.tr_frag(kt, 32 * jb, db), pb0, dq[db]);
-      dq[db] = TR::mfma32(fa.tr_frag(kt, 32 * jb + 16, db), pb1, dq[db]);
-    }
+    for (int db = 0; db < G::DB; ++db) dq[db] = second_mma<T, D>(dq[db], kt, 32 * jb, db, pb, fa);
   }
 }
 
 template <typename T, int D, int NW>
-__global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
-  typedef TileGeom<D> G;
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+  typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BN * G::ROWB;
@@ -107,7 +83,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) bwd_dq_kernel(cons
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  FragAddr<D> fa;
+  FragAddr<T, D> fa;
   fa.init(lane);
 
   const int MT = (p.N + BM - 1) / BM;
@@ -140,8 +116,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) bwd_dq_kernel(cons
         qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
         dof[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
         const u32x4 of = *reinterpret_cast<const u32x4*>(orow + (2 * kk + fa.hi) * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) delta += TR::lo(dof[kk][e]) * TR::lo(of[e]) + TR::hi(dof[kk][e]) * TR::hi(of[e]);
+        delta += dot_frag<T>(dof[kk], of);
       }
     }
     delta = xhalf_sum(delta);
@@ -169,7 +144,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) bwd_dq_kernel(cons
     if (p.d_bias != nullptr) dbias_row = p.d_bias + boff;
   }
 
-  Stager<D, BN, NT> sk, sv;
+  Stager<T, D, BN, NT> sk, sv;
   uint8_t mb = 1;
   if (nt > 0) {
     sk.load(kbase, p.k.sn, p.M, tid);
@@ -218,11 +193,11 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) bwd_dq_kernel(cons
 // dK / dV kernel
 // =============================================================================================
 template <typename T, int D, bool MASKED>
-FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<D>& fa,
-                       const u32x4 (&kf)[TileGeom<D>::KS], const u32x4 (&vf)[TileGeom<D>::KS],
-                       f32x16 (&dk)[TileGeom<D>::DB], f32x16 (&dv)[TileGeom<D>::DB], const BwdParams& p,
-                       bool key_ok, int j, int i0, int diff, int nib, const char* bias_col) {
-  typedef TileGeom<D> G;
+FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
+                       const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
+                       f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
+                       const BwdParams& p, bool key_ok, int j, int i0, int diff, int nib, const char* bias_col) {
+  typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   for (int ib = 0; ib < nib; ++ib) {
     f32x16 s, dp;
@@ -262,21 +237,20 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
         s[r] = pe * (dp[r] - dl4[e]);
       }
     }
-    const u32x4 pp0 = pack8<T>(pr, 0), pp1 = pack8<T>(pr, 1);
-    const u32x4 pd0 = pack8<T>(s, 0), pd1 = pack8<T>(s, 1);
+    SecondB<T> pp, pd;
+    pp.prep(pr);
+    pd.prep(s);
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
-      dv[db] = TR::mfma32(fa.tr_frag(dot, 32 * ib, db), pp0, dv[db]);
-      dv[db] = TR::mfma32(fa.tr_frag(dot, 32 * ib + 16, db), pp1, dv[db]);
-      dk[db] = TR::mfma32(fa.tr_frag(qt, 32 * ib, db), pd0, dk[db]);
-      dk[db] = TR::mfma32(fa.tr_frag(qt, 32 * ib + 16, db), pd1, dk[db]);
+      dv[db] = second_mma<T, D>(dv[db], dot, 32 * ib, db, pp, fa);
+      dk[db] = second_mma<T, D>(dk[db], qt, 32 * ib, db, pd, fa);
     }
   }
 }
 
 template <typename T, int D, int NW, int BMQ>
-__global__ void __launch_bounds__(NW * 64, (D <= 32 ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
-  typedef TileGeom<D> G;
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+  typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BMQ * G::ROWB;
@@ -287,7 +261,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 32 ? 2 : 1)) bwd_dkv_kernel(con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  FragAddr<D> fa;
+  FragAddr<T, D> fa;
   fa.init(lane);
 
   const int KT = (p.M + BNK - 1) / BNK;
@@ -337,7 +311,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 32 ? 2 : 1)) bwd_dkv_kernel(con
   if (p.bias != nullptr && j < p.M)
     bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + j) * (int64_t)sizeof(typename TR::elem);
 
-  Stager<D, BMQ, NT> sq, sdo;
+  Stager<T, D, BMQ, NT> sq, sdo;
   float lc_r = 0.f, dl_r = 0.f;
   auto load_tile = [&](int t) {
     const int i0 = t * BMQ;
@@ -398,7 +372,7 @@ template <typename T, int D>
 static hipError_t launch_dq_t(const BwdParams& p, hipStream_t s) {
   constexpr int NW = 4, BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
-  const size_t lds = 4 * 64 * TileGeom<D>::ROWB;
+  const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
   auto kern = bwd_dq_kernel<T, D, NW>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -408,9 +382,10 @@ static hipError_t launch_dq_t(const BwdParams& p, hipStream_t s) {
 
 template <typename T, int D>
 static hipError_t launch_dkv_t(const BwdParams& p, hipStream_t s) {
-  constexpr int NW = 4, BNK = 32 * NW, BMQ = 64;
+  constexpr int NW = 4, BNK = 32 * NW;
+  constexpr int BMQ = (Traits<T>::ES == 4 && D >= 96) ? 32 : 64;   // f32 at D >= 96: halve the staged tile (VGPR budget)
   const int KT = (p.M + BNK - 1) / BNK;
-  const size_t lds = 2 * (2 * BMQ * TileGeom<D>::ROWB + 2 * BMQ * 4);
+  const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -432,6 +407,7 @@ hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t 
   if (p.B * p.H == 0 || p.N == 0) return hipSuccess;
   if (dtype == 2) { FCSA_DISPATCH_D(launch_dq_t, BF16) }
   if (dtype == 1) { FCSA_DISPATCH_D(launch_dq_t, F16) }
+  if (dtype == 0) { FCSA_DISPATCH_D(launch_dq_t, F32) }
   return hipErrorInvalidValue;
 }
 
@@ -439,6 +415,7 @@ hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t
   if (p.B * p.H == 0 || p.M == 0) return hipSuccess;
   if (dtype == 2) { FCSA_DISPATCH_D(launch_dkv_t, BF16) }
   if (dtype == 1) { FCSA_DISPATCH_D(launch_dkv_t, F16) }
+  if (dtype == 0) { FCSA_DISPATCH_D(launch_dkv_t, F32) }
   return hipErrorInvalidValue;
 }
 

@@ -37,8 +37,6 @@ bool dim_ok(int d) { return d == 16 || d == 32 || d == 64 || d == 96 || d == 128
 int check_problem(const fcsa_problem& p) {
   if (p.dtype != FCSA_F16 && p.dtype != FCSA_BF16 && p.dtype != FCSA_F32)
     return fail(FCSA_ERR_UNSUPPORTED, "unsupported dtype %d (expected f32=0, f16=1, bf16=2)", p.dtype);
-  if (p.dtype == FCSA_F32)
-    return fail(FCSA_ERR_UNSUPPORTED, "float32 kernels are not built in this version of libfcsa_hip (f16/bf16 only)");
   if (!dim_ok(p.dim_head))
     return fail(FCSA_ERR_UNSUPPORTED, "dim_head %d not in {16, 32, 64, 96, 128}", p.dim_head);
   if (p.batch < 0 || p.heads < 0 || p.q_len < 0 || p.k_len < 0)
@@ -189,7 +187,7 @@ int fcsa_profile_collect(fcsa_kernel_stat* stats, int32_t capacity) {
 int fcsa_debug(char* buf, size_t buf_bytes) {
   if (buf != nullptr && buf_bytes > 0) {
     snprintf(buf, buf_bytes,
-             "libfcsa_hip abi=%d arch=gfx950 dtypes=f16,bf16 dim_head=16,32,64,96,128 "
+             "libfcsa_hip abi=%d arch=gfx950 dtypes=f32,f16,bf16 dim_head=16,32,64,96,128 "
              "kernels=l2norm,fwd(32x32x16 mfma, 128x64 tile),bwd_dq(128x64),bwd_dkv(128 keys x 64 rows),finalize",
              FCSA_ABI_VERSION);
   }
@@ -198,14 +196,15 @@ int fcsa_debug(char* buf, size_t buf_bytes) {
 
 int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_t dim_head, int32_t groups,
                 const fcsa_tensor* x, void* xn, float* inv_norm, void* stream) {
-  if (dtype != FCSA_F16 && dtype != FCSA_BF16) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dtype %d not supported", dtype);
+  if (dtype != FCSA_F16 && dtype != FCSA_BF16 && dtype != FCSA_F32) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dtype %d not supported", dtype);
   if (x == nullptr || xn == nullptr) return fail(FCSA_ERR_INVALID_ARG, "fcsa_l2norm: null argument");
   if (dim_head <= 0 || dim_head % 8 != 0) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dim_head %d must be a multiple of 8", dim_head);
   if (dim_head > 512) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dim_head %d > 512", dim_head);
   if (groups < 1 || dim_head % groups != 0) return fail(FCSA_ERR_INVALID_ARG, "fcsa_l2norm: groups (%d) must divide dim_head (%d)", groups, dim_head);
-  if (int rc = check_tensor("x", *x, 2, true)) return rc;
+  const int es = elem_size(dtype);
+  if (int rc = check_tensor("x", *x, es, true)) return rc;
   fcsa::NormParams np;
-  np.x = view(*x, 2);
+  np.x = view(*x, es);
   np.xn = static_cast<char*>(xn);
   np.inv_norm = inv_norm;
   np.B = batch; np.H = heads; np.L = len; np.D = dim_head; np.G = groups;

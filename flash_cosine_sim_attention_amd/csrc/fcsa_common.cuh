@@ -1,23 +1,27 @@
 // fcsa_common.cuh -- device building blocks shared by the gfx950 cosine-sim attention kernels.
 //
 // Everything here is written for CDNA4 (wave64, v_mfma_f32_32x32x16_{bf16,f16},
-// ds_read_b64_tr_b16, 160 KiB LDS with 64 dword banks).  It replaces the reference's
-// mem::shared_fragment (cu:89-258), mma::warp_tile (cu:604-1067), rowsum_accumulator
+// v_mfma_f32_32x32x2_f32, ds_read_b64_tr_b16, 160 KiB LDS with 64 dword banks).  It replaces the
+// reference's mem::shared_fragment (cu:89-258), mma::warp_tile (cu:604-1067), rowsum_accumulator
 // (cu:262-316) and layout:: tables (cu:320-597) with a different decomposition:
 //
 //   * One wave owns 32 sequence positions ("row-per-lane"): every tile product is issued so
 //     that the MFMA C operand has  column = lane & 31 = the wave's own sequence position  and
 //     rows = the other index.  Per-row scalars (row sum, 1/l, delta, norms) are then per-lane
 //     scalars and the row reductions are a single cross-half add (lane ^ 32).
-//   * C layout of v_mfma_f32_32x32x16 (guide §3): value r of lane l is
-//         row  R(r, l>>5) = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),   col = l & 31.
-//     A/B operands: lane l holds 8 consecutive k for row/col (l & 31): k = 8 * (l >> 5) + e.
-//     A 32x32 f32 result is turned into the 16-bit B operand of the NEXT product without any
-//     cross-lane traffic: registers r = 8*ks + e (e = 0..7) of a lane are exactly k-slot
-//     (l>>5, e) of k-step ks if the other operand enumerates the contraction index in the order
-//         idx(ks, hi, e) = 16*ks + 8*(e >> 2) + 4*hi + (e & 3).
-//     That other operand always comes from a row-major LDS tile through two
-//     ds_read_b64_tr_b16 (rows idx(ks,hi,0..3) and idx(ks,hi,4..7)).
+//   * C layout of the 32x32 MFMAs (guide §3, dtype independent): value r of lane l is
+//         row  crow(r, l>>5) = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),   col = l & 31.
+//   * 16-bit operands (v_mfma_f32_32x32x16): lane l holds 8 consecutive k of row/col (l & 31):
+//     k = 8 * (l >> 5) + e.  A 32x32 f32 result becomes the 16-bit B operand of the NEXT product
+//     without any cross-lane traffic: registers r = 8*ks + e (e = 0..7) of a lane are exactly
+//     k-slot (l>>5, e) of k-step ks if the other operand enumerates the contraction index as
+//         idx(ks, hi, e) = 16*ks + 8*(e >> 2) + 4*hi + (e & 3)        ( = crow(8*ks + e, hi) ).
+//     That other operand comes from a row-major LDS tile through two ds_read_b64_tr_b16
+//     (rows idx(ks,hi,0..3) and idx(ks,hi,4..7)).
+//   * f32 operands (v_mfma_f32_32x32x2, exact f32): lane l holds ONE k = l >> 5 per instruction.
+//     A 16-byte row fragment (4 floats: features 8*kk + 4*hi + t) feeds 4 instructions (t = 0..3);
+//     the second product takes register t of the f32 result directly as B and one ds_read_b32
+//     (row crow(t, hi) of the LDS tile) as A -- no conversion, no transposed read.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,18 +40,18 @@ typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
 
 #define FCSA_DEV __device__ __forceinline__
 
-constexpr float kLog2e = 1.4426950408889634f;
-
 // ---------------------------------------------------------------------------------------------
 // dtype traits
 // ---------------------------------------------------------------------------------------------
 struct BF16 {};
 struct F16 {};
+struct F32 {};
 
 template <typename T> struct Traits;
 
 template <> struct Traits<BF16> {
   typedef __bf16 elem;
+  static constexpr int ES = 2;
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
@@ -61,6 +65,7 @@ template <> struct Traits<BF16> {
 
 template <> struct Traits<F16> {
   typedef _Float16 elem;
+  static constexpr int ES = 2;
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -72,44 +77,76 @@ template <> struct Traits<F16> {
   static FCSA_DEV float hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
 };
 
+template <> struct Traits<F32> {
+  typedef float elem;
+  static constexpr int ES = 4;
+  // 4 x v_mfma_f32_32x32x2_f32 over the 4 floats of a 16-byte fragment
+  static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[t]), __builtin_bit_cast(float, b[t]), c, 0, 0, 0);
+    return c;
+  }
+};
+
 // row index (0..31) of accumulator register r for lane half hi
 FCSA_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// <a, b> over the elements of two 16-byte fragments
+template <typename T> FCSA_DEV float dot_frag(const u32x4& a, const u32x4& b) {
+  float s = 0.f;
+  if constexpr (Traits<T>::ES == 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += __builtin_bit_cast(float, a[e]) * __builtin_bit_cast(float, b[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += Traits<T>::lo(a[e]) * Traits<T>::lo(b[e]) + Traits<T>::hi(a[e]) * Traits<T>::hi(b[e]);
+  }
+  return s;
+}
+
 // ---------------------------------------------------------------------------------------------
-// LDS tile geometry: row-major [rows][D] 16-bit tile, 16-byte chunks XOR-swizzled per row so that
-//   (a) ds_read_b128 of one chunk column by 16 different rows      (MFMA A/B fragments) and
-//   (b) ds_read_b64_tr_b16 of 4 consecutive rows x 64 contiguous B (transposed fragments)
-// are both bank-conflict free (64 banks x 4 B; derivation in DESIGN.md §LDS).
+// LDS tile geometry: row-major [rows][D] tile of ES-byte elements, 16-byte chunks XOR-swizzled per
+// row so that
+//   (a) ds_read_b128 of one chunk column by 16 different rows      (MFMA row fragments) and
+//   (b) ds_read_b64_tr_b16 of 4 consecutive rows x 64 contiguous B (transposed fragments, 16 bit)
+// are both bank-conflict free (64 banks x 4 B; derivation in DESIGN.md §LDS).  ds_read_b32 of 32
+// consecutive floats of one row (f32 second product) is conflict free under any chunk permutation.
 // ---------------------------------------------------------------------------------------------
-template <int D> struct TileGeom {
+template <int D, int ES> struct TileGeom {
   static_assert(D == 16 || D == 32 || D == 64 || D == 96 || D == 128, "dim_head");
-  static constexpr int KS = D / 16;                  // 16-wide contraction steps over the feature dim
+  static constexpr int CPR = D * ES / 16;            // valid 16-byte chunks per row
+  static constexpr int KS = CPR / 2;                 // row-fragment steps over the feature dim (2 chunks each)
   static constexpr int DB = (D + 31) / 32;           // 32-wide feature blocks of an output tile
-  static constexpr int CPR = D / 8;                  // valid 16-byte chunks per row
-  static constexpr int RSC = D <= 16 ? 2 : D <= 32 ? 4 : D <= 64 ? 8 : 16;   // chunks per LDS row (pow2)
+  static constexpr int RSC = CPR <= 2 ? 2 : CPR <= 4 ? 4 : CPR <= 8 ? 8 : CPR <= 16 ? 16 : 32;   // chunks per LDS row
   static constexpr int ROWB = RSC * 16;              // LDS row pitch in bytes
 
   static FCSA_DEV int swz(int row) {
     if constexpr (RSC == 2) return (row >> 3) & 1;
     else if constexpr (RSC == 4) return (row >> 2) & 3;
     else if constexpr (RSC == 8) { int t = (row >> 1) & 7; return ((t & 1) << 2) | (t >> 1); }
-    else return ((row & 3) << 2) | ((row >> 2) & 3);
+    else if constexpr (RSC == 16) return ((row & 3) << 2) | ((row >> 2) & 3);
+    else return row & 15;
   }
   // byte offset of 16-byte chunk `chunk` of row `row`
   static FCSA_DEV int off(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
 
-// Per-lane offsets for reading fragments out of a TileGeom<D> tile.
-//   row-fragment (ds_read_b128): lane (x = l&31, hi) reads row (rbase + x), features 16*kk + 8*hi .. +8
-//   transposed fragment (2 x ds_read_b64_tr_b16): lane (x = l&31, hi) receives, for feature
-//   column c = 32*db + x, the 8 rows rbase + idx(ks, hi, e), e = 0..7.
-template <int D> struct FragAddr {
-  typedef TileGeom<D> G;
+// Per-lane offsets for reading fragments out of a TileGeom tile.
+//   row fragment (ds_read_b128): lane (x = l&31, hi) reads row (rbase + x), 16-byte chunk 2*kk + hi
+//   transposed fragment, 16 bit (2 x ds_read_b64_tr_b16): lane (x, hi) receives, for feature column
+//   c = 32*db + x, the 8 rows rbase + idx(0, hi, e), e = 0..7
+//   scalar, f32 (ds_read_b32): lane (x, hi) reads element (rbase + crow(t, hi), 32*db + x)
+template <typename T, int D> struct FragAddr {
+  static constexpr int ES = Traits<T>::ES;
+  typedef TileGeom<D, ES> G;
   int row_off;        // (l&31) * ROWB
   int row_swz;        // swz(l&31)
-  int tr_off[2];      // byte offset (excluding rbase/ks/db terms) for the two 4-row halves
-  int tr_swz[2];      // swizzle value of the row this lane ADDRESSES in each half
-  int tr_col;         // chunk index contribution of this lane: 2*((l>>4)&1) + ((l&3)>>1)   (+4*db at use)
+  int tr_off[2];      // 16 bit: byte offset (excluding rbase/db terms) for the two 4-row halves
+  int tr_swz[2];      // 16 bit: swizzle of the row this lane ADDRESSES in each half
+  int tr_col;         // 16 bit: chunk contribution of this lane: 2*((l>>4)&1) + ((l&3)>>1)   (+4*db at use)
+  int sc_chunk;       // f32: chunk of column x within a 32-column block: x >> 2 (+8*db at use)
+  int sc_byte;        // f32: byte inside the chunk: (x & 3) * 4
   int hi;
 
   FCSA_DEV void init(int lane) {
@@ -125,15 +162,18 @@ template <int D> struct FragAddr {
     for (int half = 0; half < 2; ++half) {
       const int r = 8 * half + 4 * hi + (t >> 2);      // row within a 16-row k-step
       tr_off[half] = r * G::ROWB + ((t & 1) << 3);
-      tr_swz[half] = G::swz(r);                          // independent of 16*ks and 32*jb (see TileGeom)
+      tr_swz[half] = G::swz(r);                          // independent of the 16-row step and the 32-row block
     }
+    const int xc = (D >= 32) ? x : (x & 15);             // D = 16: columns 16..31 do not exist, re-read 0..15
+    sc_chunk = xc >> 2;
+    sc_byte = (xc & 3) << 2;
   }
-  // A/B fragment of row (rbase + x): rbase must be a multiple of 32
+  // row fragment of row (rbase + x): rbase must be a multiple of 32
   FCSA_DEV u32x4 row_frag(const char* tile, int rbase, int kk) const {
     const int chunk = 2 * kk + hi;
     return *reinterpret_cast<const u32x4*>(tile + rbase * G::ROWB + row_off + ((chunk ^ row_swz) << 4));
   }
-  // transposed fragment: rows rbase + idx(0, hi, e) (rbase multiple of 16), feature block db
+  // 16 bit: transposed fragment, rows rbase + idx(0, hi, e) (rbase multiple of 16), feature block db
   FCSA_DEV u32x4 tr_frag(const char* tile, int rbase, int db) const {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     u32x4 out;
@@ -148,14 +188,51 @@ template <int D> struct FragAddr {
     }
     return out;
   }
+  // f32: element (rbase + crow(t, hi), 32*db + x); rbase multiple of 32
+  FCSA_DEV float scalar(const char* tile, int rbase, int t, int db) const {
+    const int row = crow(t, 0) + 4 * hi;
+    return *reinterpret_cast<const float*>(tile + (rbase + row) * G::ROWB + (((8 * db + sc_chunk) ^ G::swz(row)) << 4) + sc_byte);
+  }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Second product of a pair:  acc[32 features x 32 own positions] += tile^T[features][rows] * P[rows][own]
+// where P is a 32x32 f32 result held in the C layout.  16 bit: P is packed once (SecondB) and the tile
+// operand comes through transposed reads; f32: P registers are used as they are.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct SecondB {
+  u32x4 v[2];
+  FCSA_DEV void prep(const f32x16& p) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[ks][e] = Traits<T>::pack2(p[8 * ks + 2 * e], p[8 * ks + 2 * e + 1]);
+  }
+};
+template <> struct SecondB<F32> {
+  f32x16 p;
+  FCSA_DEV void prep(const f32x16& x) { p = x; }
+};
+
+template <typename T, int D>
+FCSA_DEV f32x16 second_mma(f32x16 acc, const char* tile, int rbase, int db, const SecondB<T>& b, const FragAddr<T, D>& fa) {
+  if constexpr (Traits<T>::ES == 4) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.scalar(tile, rbase, t, db), b.p[t], acc, 0, 0, 0);
+  } else {
+    acc = Traits<T>::mfma32(fa.tr_frag(tile, rbase, db), b.v[0], acc);
+    acc = Traits<T>::mfma32(fa.tr_frag(tile, rbase + 16, db), b.v[1], acc);
+  }
+  return acc;
+}
 
 // ---------------------------------------------------------------------------------------------
 // global -> registers -> LDS staging of a [ROWS][D] tile by NT threads (split issue / write, so the
 // HBM/L2 latency hides under the MFMA phase in between: guide T14)
 // ---------------------------------------------------------------------------------------------
-template <int D, int ROWS, int NT> struct Stager {
-  typedef TileGeom<D> G;
+template <typename T, int D, int ROWS, int NT> struct Stager {
+  typedef TileGeom<D, Traits<T>::ES> G;
   static constexpr int NCH = ROWS * G::CPR;
   static constexpr int PER = (NCH + NT - 1) / NT;
   u32x4 r[PER];
@@ -182,12 +259,27 @@ template <int D, int ROWS, int NT> struct Stager {
   }
 };
 
-// pack registers 8*ks .. 8*ks+7 of a 32x32 f32 result into the 16-bit operand of k-step ks
-template <typename T> FCSA_DEV u32x4 pack8(const f32x16& p, int ks) {
-  u32x4 o;
+// Store the C-layout accumulators of a [32 own positions x D] tile: lane (row, hi) holds features
+// 32*db + 8*rq + 4*hi + 0..3.  Output element type: float (as_f32 or T = F32) or the 16-bit T.
+template <typename T, int D>
+FCSA_DEV void store_row_tile(char* row, const f32x16 (&acc)[TileGeom<D, Traits<T>::ES>::DB], float mul, int hi, bool as_f32) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = Traits<T>::pack2(p[8 * ks + 2 * e], p[8 * ks + 2 * e + 1]);
-  return o;
+  for (int db = 0; db < TileGeom<D, Traits<T>::ES>::DB; ++db)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      if (32 * db + 8 * rq < D) {                 // compile-time after unrolling (D % 8 == 0)
+        const int d0 = 32 * db + 8 * rq + 4 * hi;
+        if (Traits<T>::ES == 4 || as_f32) {
+          f32x4 v = {acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul, acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul};
+          *reinterpret_cast<f32x4*>(row + d0 * 4) = v;
+        } else if constexpr (Traits<T>::ES == 2) {
+          u32x2 v;
+          v[0] = Traits<T>::pack2(acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul);
+          v[1] = Traits<T>::pack2(acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul);
+          *reinterpret_cast<u32x2*>(row + d0 * 2) = v;
+        }
+      }
+    }
 }
 
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

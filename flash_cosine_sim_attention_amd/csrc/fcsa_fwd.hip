@@ -1,4 +1,4 @@
-// fcsa_fwd.hip -- forward kernel of fused cosine-similarity attention for gfx950 (f16 / bf16).
+// fcsa_fwd.hip -- forward kernel of fused cosine-similarity attention for gfx950 (f16 / bf16 / f32).
 //
 // Replaces forward_kernel (reference cu:1072-1247).  Math (cu:1204-1246):
 //     S = scale * Qh Kh^T (+ bias);  P~ = valid ? exp(S - shift) : 0;  l = rowsum(P~);
@@ -14,17 +14,19 @@
 //   * exp2 + masking + row-sum stay in registers; P~ is packed to 16 bit in place and becomes the
 //     B operand of O^T = V^T P~^T, whose A operand V^T comes from the row-major LDS V tile through
 //     ds_read_b64_tr_b16 (no P~ round trip through shared memory, cf. cu:1222);
-//   * the row sum is a per-lane f32 accumulation of the UN-rounded P~ plus one lane^32 add.
+//   * the row sum is a per-lane f32 accumulation of the UN-rounded P~ plus one lane^32 add;
+//   * float32 inputs run the same skeleton on v_mfma_f32_32x32x2_f32 (exact f32, 1/16 of the bf16
+//     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read.
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
 
 namespace fcsa {
 
 template <typename T, int D, int NW, bool MASKED>
-FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<D>& fa, const u32x4 (&qf)[TileGeom<D>::KS],
-                       f32x16 (&o)[TileGeom<D>::DB], float& l, const FwdParams& p, uint64_t word, int i, int j0,
-                       int diff, const char* bias_row) {
-  typedef TileGeom<D> G;
+FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
+                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
+                       float& l, const FwdParams& p, uint64_t word, int i, int j0, int diff, const char* bias_row) {
+  typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
@@ -55,18 +57,16 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<D>& fa, co
       l += e;
       s[r] = e;
     }
-    const u32x4 pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 1);
+    SecondB<T> pb;
+    pb.prep(s);
 #pragma unroll
-    for (int db = 0; db < G::DB; ++db) {
-      o[db] = TR::mfma32(fa.tr_frag(vt, 32 * jb, db), pb0, o[db]);
-      o[db] = TR::mfma32(fa.tr_frag(vt, 32 * jb + 16, db), pb1, o[db]);
-    }
+    for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
   }
 }
 
 template <typename T, int D, int NW>
-__global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) fwd_kernel(const FwdParams p) {
-  typedef TileGeom<D> G;
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) fwd_kernel(const FwdParams p) {
+  typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BN * G::ROWB;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) fwd_kernel(const F
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  FragAddr<D> fa;
+  FragAddr<T, D> fa;
   fa.init(lane);
 
   const int MT = (p.N + BM - 1) / BM;
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) fwd_kernel(const F
   if (p.bias != nullptr && i < p.N)
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + i) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
 
-  Stager<D, BN, NT> sk, sv;
+  Stager<T, D, BN, NT> sk, sv;
   uint8_t mb = 1;
   if (nt > 0) {
     sk.load(kbase, p.k.sn, p.M, tid);
@@ -164,18 +164,7 @@ __global__ void __launch_bounds__(NW * 64, (D <= 64 ? 2 : 1)) fwd_kernel(const F
   if (i < p.N) {
     if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = inv;
     char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
-#pragma unroll
-    for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = 32 * db + 8 * rq + 4 * fa.hi;
-        if (32 * db + 8 * rq < D) {     // compile-time after unrolling (D % 8 == 0)
-          u32x2 v;
-          v[0] = TR::pack2(o[db][4 * rq] * inv, o[db][4 * rq + 1] * inv);
-          v[1] = TR::pack2(o[db][4 * rq + 2] * inv, o[db][4 * rq + 3] * inv);
-          *reinterpret_cast<u32x2*>(orow + d0 * 2) = v;
-        }
-      }
+    store_row_tile<T, D>(orow, o, inv, fa.hi, false);
   }
 }
 
@@ -184,7 +173,7 @@ static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
-  const size_t lds = 4 * 64 * TileGeom<D>::ROWB;
+  const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
   auto kern = fwd_kernel<T, D, NW>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -208,6 +197,7 @@ hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s) {
   if (p.B * p.H == 0 || p.N == 0) return hipSuccess;
   if (dtype == 2) return launch_fwd_d<BF16>(D, p, s);
   if (dtype == 1) return launch_fwd_d<F16>(D, p, s);
+  if (dtype == 0) return launch_fwd_d<F32>(D, p, s);
   return hipErrorInvalidValue;
 }
 

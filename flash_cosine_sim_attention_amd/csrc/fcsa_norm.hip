@@ -15,15 +15,29 @@
 
 namespace fcsa {
 
-template <typename T> FCSA_DEV void unpack8(const u32x4& u, float (&f)[8]) {
+// 8 consecutive elements of type T <-> 8 floats (16 bytes for f16/bf16, 32 bytes for f32)
+template <typename T> FCSA_DEV void load8(const char* p, float (&f)[8]) {
+  if constexpr (Traits<T>::ES == 4) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { f[2 * e] = Traits<T>::lo(u[e]); f[2 * e + 1] = Traits<T>::hi(u[e]); }
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+  } else {
+    const u32x4 u = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = Traits<T>::lo(u[e]); f[2 * e + 1] = Traits<T>::hi(u[e]); }
+  }
 }
-template <typename T> FCSA_DEV u32x4 pack8f(const float (&f)[8]) {
-  u32x4 u;
+template <typename T> FCSA_DEV void store8(char* p, const float (&f)[8]) {
+  if constexpr (Traits<T>::ES == 4) {
+    f32x4 a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
+    reinterpret_cast<f32x4*>(p)[0] = a;
+    reinterpret_cast<f32x4*>(p)[1] = b;
+  } else {
+    u32x4 u;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) u[e] = Traits<T>::pack2(f[2 * e], f[2 * e + 1]);
-  return u;
+    for (int e = 0; e < 4; ++e) u[e] = Traits<T>::pack2(f[2 * e], f[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(p) = u;
+  }
 }
 
 // sum `v` over the LPG consecutive lanes [base, base + LPG) this lane belongs to
@@ -72,8 +86,7 @@ __global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) {
     bh = m.row / p.L;
     l = (int)(m.row - bh * p.L);
     const int b = (int)(bh / p.H), h = (int)(bh - (int64_t)b * p.H);
-    const u32x4 u = *reinterpret_cast<const u32x4*>(p.x.p + (int64_t)b * p.x.sb + (int64_t)h * p.x.sh + (int64_t)l * p.x.sn + m.c * 16);
-    unpack8<T>(u, f);
+    load8<T>(p.x.p + (int64_t)b * p.x.sb + (int64_t)h * p.x.sh + (int64_t)l * p.x.sn + m.c * 8 * Traits<T>::ES, f);
   }
   float ss = 0.f;
 #pragma unroll
@@ -83,7 +96,7 @@ __global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) {
   if (m.active) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] *= inv;
-    *reinterpret_cast<u32x4*>(p.xn + (m.row * p.D + m.c * 8) * 2) = pack8f<T>(f);
+    store8<T>(p.xn + (m.row * p.D + m.c * 8) * Traits<T>::ES, f);
     if (p.inv_norm != nullptr && (m.c % lpg) == 0) p.inv_norm[m.row * p.G + m.c / lpg] = inv;
   }
 }
@@ -139,12 +152,12 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) 
         for (int e = 0; e < 4; ++e) { g[e] += a[e]; g[4 + e] += c[e]; }
       } else {
         float t[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(p.slab + (srow * p.D + m.c * 8) * 2), t);
+        load8<T>(p.slab + (srow * p.D + m.c * 8) * Traits<T>::ES, t);
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] += t[e];
       }
     }
-    if (norm) unpack8<T>(*reinterpret_cast<const u32x4*>(p.xn + (m.row * p.D + m.c * 8) * 2), xh);
+    if (norm) load8<T>(p.xn + (m.row * p.D + m.c * 8) * Traits<T>::ES, xh);
   }
   if (norm) {
     float dot = 0.f;
@@ -159,7 +172,7 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) 
     }
   }
   if (m.active)
-    *reinterpret_cast<u32x4*>(p.dx.p + (int64_t)b * p.dx.sb + (int64_t)h * p.dx.sh + (int64_t)l * p.dx.sn + m.c * 16) = pack8f<T>(g);
+    store8<T>(p.dx.p + (int64_t)b * p.dx.sb + (int64_t)h * p.dx.sh + (int64_t)l * p.dx.sn + m.c * 8 * Traits<T>::ES, g);
 }
 
 // finalize, any group size: one thread per (row, group)
@@ -235,12 +248,14 @@ static hipError_t launch_l2norm_bwd_t(const NormBwdParams& p, hipStream_t s) {
 hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s) {
   if (dtype == 2) return launch_l2norm_t<BF16>(p, s);
   if (dtype == 1) return launch_l2norm_t<F16>(p, s);
+  if (dtype == 0) return launch_l2norm_t<F32>(p, s);
   return hipErrorInvalidValue;
 }
 
 hipError_t launch_l2norm_bwd(int dtype, const NormBwdParams& p, hipStream_t s) {
   if (dtype == 2) return launch_l2norm_bwd_t<BF16>(p, s);
   if (dtype == 1) return launch_l2norm_bwd_t<F16>(p, s);
+  if (dtype == 0) return launch_l2norm_bwd_t<F32>(p, s);
   return hipErrorInvalidValue;
 }
 

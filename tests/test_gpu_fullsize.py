@@ -66,11 +66,12 @@ def test_forward_fullsize_vs_f32_slices_and_identities(name):
     o = F.flash_cosine_sim_attention(q, k, v, **kw)
     assert torch.isfinite(o).all()
     atol = 2e-3 if cfg["dtype"] == torch.float16 else 1.5e-2
+    rtol = 2.0 ** -10 if cfg["dtype"] == torch.float16 else 2.0 ** -7      # one output ulp
     single = k.dim() == 3
     for (b, h) in ((0, 0), (cfg["q"][0] - 1, cfg["q"][1] - 1), (0, 3)):
         kk, vv = (k[b], v[b]) if single else (k[b, h], v[b, h])
         ref = _ref_slice(q[b, h], kk, vv, None if mask is None else mask[b], cfg["causal"], cfg["scale"], cfg["groups"])
-        err = (o[b, h].float() - ref).abs().max().item()
+        err = ((o[b, h].float() - ref).abs() - rtol * ref.abs()).max().item()
         assert err <= atol, f"{name} slice {(b, h)} max-abs {err:.3e}"
     # rows of P sum to one
     ones = torch.ones_like(v)
