@@ -28,7 +28,7 @@ namespace fcsa {
 // =============================================================================================
 // dQ kernel
 // =============================================================================================
-template <typename T, int D, bool MASKED>
+template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
                       f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
@@ -51,18 +51,25 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       if (p.causal) w &= le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi));
     }
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
+    float bv[16];
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = min(jbase + crow(r, 0), p.M - 1);
+        bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float x = s[r] * p.c1 + lc;
-      const int j = jbase + crow(r, 0);
-      if (bias_row != nullptr && j < p.M) {
-        const typename TR::elem bv = reinterpret_cast<const typename TR::elem*>(bias_row)[j];
-        x += (float)bv * p.bias_c;
-      }
+      if constexpr (BIAS) x += bv[r];
       float e = fast_exp2(x);
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
       const float ds = e * (dp[r] - delta);
-      if (dbias_row != nullptr && j < p.M && ds != 0.f) atomicAdd(dbias_row + j, ds);   // cu:1574-1576
+      if constexpr (BIAS) {
+        const int j = jbase + crow(r, 0);
+        if (dbias_row != nullptr && j < p.M && ds != 0.f) atomicAdd(dbias_row + j, ds);   // cu:1574-1576
+      }
       s[r] = ds;
     }
     SecondB<T> pb;
@@ -136,12 +143,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
-  const char* bias_row = nullptr;
-  float* dbias_row = nullptr;
-  if (i < p.N) {
-    const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + i) * (int64_t)p.M;
-    if (p.bias != nullptr) bias_row = p.bias + boff * (int64_t)sizeof(typename TR::elem);
-    if (p.d_bias != nullptr) dbias_row = p.d_bias + boff;
+  const bool has_bias = p.bias != nullptr;        // wave-uniform (kernel argument)
+  const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
+  float* dbias_row = nullptr;                     // only for real rows
+  if (has_bias) {
+    const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M;
+    bias_row = p.bias + boff * (int64_t)sizeof(typename TR::elem);
+    if (p.d_bias != nullptr && i < p.N) dbias_row = p.d_bias + boff;
   }
 
   Stager<T, D, BN, NT> sk, sv;
@@ -173,8 +181,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
     const bool skip = p.causal && (j0 > mw + 31 + diff);
     const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
     if (!skip) {
-      if (masked) dq_tile<T, D, true>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
-      else        dq_tile<T, D, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
+      if (has_bias)    dq_tile<T, D, true, true>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
+      else if (masked) dq_tile<T, D, true, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
+      else             dq_tile<T, D, false, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
     }
     if (more) {
       sk.store(knxt, tid);
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
 // =============================================================================================
 // dK / dV kernel
 // =============================================================================================
-template <typename T, int D, bool MASKED>
+template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
@@ -223,13 +232,11 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * rq + e;
         float x = s[r] * p.c1 + lc4[e];
-        if (bias_col != nullptr) {
-          const int i = i0 + 32 * ib + crow(r, 0) + 4 * fa.hi;
-          if (i < p.N) {
-            const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
-                bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
-            x += (float)bv * p.bias_c;
-          }
+        if constexpr (BIAS) {   // clamped row: always a valid address; rows >= N have P = 0 through lc = -inf
+          const int i = min(i0 + 32 * ib + crow(r, 0) + 4 * fa.hi, p.N - 1);
+          const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
+              bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
+          x += (float)bv * p.bias_c;
         }
         float pe = fast_exp2(x);
         if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
@@ -307,9 +314,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
   const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
-  const char* bias_col = nullptr;
-  if (p.bias != nullptr && j < p.M)
-    bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + j) * (int64_t)sizeof(typename TR::elem);
+  const bool has_bias = p.bias != nullptr;        // wave-uniform (kernel argument)
+  const char* bias_col = nullptr;                 // column min(j, M-1): always a valid address
+  if (has_bias)
+    bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
 
   Stager<T, D, BMQ, NT> sq, sdo;
   float lc_r = 0.f, dl_r = 0.f;
@@ -352,8 +360,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
     if (!skip) {
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
-      if (masked) dkv_tile<T, D, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
-      else        dkv_tile<T, D, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
+      if (has_bias)    dkv_tile<T, D, true, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
+      else if (masked) dkv_tile<T, D, true, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
+      else             dkv_tile<T, D, false, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
     }
     if (more) store_tile(nxt);
     __syncthreads();

@@ -22,7 +22,7 @@
 
 namespace fcsa {
 
-template <typename T, int D, int NW, bool MASKED>
+template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, const FwdParams& p, uint64_t word, int i, int j0, int diff, const char* bias_row) {
@@ -42,16 +42,20 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       if (p.causal) w &= le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi));
     }
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
+    float bv[16];
+    if constexpr (BIAS) {
+      // unconditional loads from clamped (always valid) addresses; out-of-range positions are masked below
+      // or never stored, so their value is irrelevant.  bias_row already points at a valid row.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = min(jbase + crow(r, 0), p.M - 1);
+        bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float x = s[r] * p.c1 - p.c2;
-      if (bias_row != nullptr) {
-        const int j = jbase + crow(r, 0);
-        if (j < p.M) {
-          const typename TR::elem bv = reinterpret_cast<const typename TR::elem*>(bias_row)[j];
-          x += (float)bv * p.bias_c;
-        }
-      }
+      if constexpr (BIAS) x += bv[r];
       float e = fast_exp2(x);
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
       l += e;
@@ -115,9 +119,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
-  const char* bias_row = nullptr;
-  if (p.bias != nullptr && i < p.N)
-    bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + i) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
+  const bool has_bias = p.bias != nullptr;        // wave-uniform (kernel argument)
+  const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
+  if (has_bias)
+    bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
 
   Stager<T, D, BN, NT> sk, sv;
   uint8_t mb = 1;
@@ -148,8 +153,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
     const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
     if (!skip) {
-      if (masked) fwd_tile<T, D, NW, true>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
-      else        fwd_tile<T, D, NW, false>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
+      if (has_bias)    fwd_tile<T, D, true, true>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
+      else if (masked) fwd_tile<T, D, true, false>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
+      else             fwd_tile<T, D, false, false>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
     }
     if (more) {
       sk.store(knxt, tid);
