@@ -40,6 +40,11 @@ typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
 
 #define FCSA_DEV __device__ __forceinline__
 
+// NOTE: always pass vector ELEMENTS through this by-value helper.  `__builtin_bit_cast(float, v[t])`
+// applied directly to an ext_vector element lvalue is miscompiled by hipcc 7.2 (it reads element 0
+// for every t: observed as four v_mfma_f32_32x32x2_f32 with identical operand registers).
+FCSA_DEV float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+
 // ---------------------------------------------------------------------------------------------
 // dtype traits
 // ---------------------------------------------------------------------------------------------
@@ -59,8 +64,8 @@ template <> struct Traits<BF16> {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(uint32_t, v);
   }
-  static FCSA_DEV float lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-  static FCSA_DEV float hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+  static FCSA_DEV float lo(uint32_t u) { return as_f32(u << 16); }
+  static FCSA_DEV float hi(uint32_t u) { return as_f32(u & 0xffff0000u); }
 };
 
 template <> struct Traits<F16> {
@@ -84,7 +89,7 @@ template <> struct Traits<F32> {
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[t]), __builtin_bit_cast(float, b[t]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(as_f32(a[t]), as_f32(b[t]), c, 0, 0, 0);
     return c;
   }
 };
@@ -97,7 +102,7 @@ template <typename T> FCSA_DEV float dot_frag(const u32x4& a, const u32x4& b) {
   float s = 0.f;
   if constexpr (Traits<T>::ES == 4) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s += __builtin_bit_cast(float, a[e]) * __builtin_bit_cast(float, b[e]);
+    for (int e = 0; e < 4; ++e) s += as_f32(a[e]) * as_f32(b[e]);
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) s += Traits<T>::lo(a[e]) * Traits<T>::lo(b[e]) + Traits<T>::hi(a[e]) * Traits<T>::hi(b[e]);

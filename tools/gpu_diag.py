@@ -71,10 +71,40 @@ def run(dtype, b, h, n, m, d, causal=False, grads=True, v_mode="rand", seed=0, l
         P("  EXCEPTION:\n" + traceback.format_exc())
 
 
+def norm_check(dtype, d, groups=1):
+    from flash_cosine_sim_attention_amd import _core
+    torch.manual_seed(5)
+    x = torch.randn(2, 3, 37, d, device="cuda", dtype=dtype)
+    try:
+        got = _core.l2norm_device(x, groups)
+        ref = O.l2norm(npf(x), groups)
+        P(f"l2norm {dtype} D{d} G{groups}: max-abs {np.abs(npf(got) - ref).max():.3e}")
+    except Exception:
+        P("  l2norm EXCEPTION:\n" + traceback.format_exc())
+
+
 def main():
     P("device:", torch.cuda.get_device_name(0), "| torch", torch.__version__)
     P(F.debug())
     bf, hf = torch.bfloat16, torch.float16
+    if os.environ.get("FCSA_DIAG", "") == "f32":
+        f32 = torch.float32
+        for d in (16, 32, 64, 128):
+            norm_check(f32, d)
+        norm_check(bf, 64)
+        run(f32, 1, 1, 32, 32, 64, grads=False, v_mode="ones", l2norm=False)
+        run(f32, 1, 1, 32, 32, 64, grads=False, v_mode="onehot", l2norm=False)
+        run(f32, 1, 1, 32, 32, 64, grads=False, l2norm=False)
+        run(f32, 1, 1, 32, 32, 64, grads=False)
+        run(f32, 1, 1, 32, 32, 32, grads=False, l2norm=False)
+        run(f32, 1, 1, 32, 32, 16, grads=False, l2norm=False)
+        run(f32, 1, 1, 128, 256, 64, grads=False)
+        run(f32, 1, 1, 32, 32, 64, l2norm=False)
+        run(f32, 1, 2, 128, 256, 64)
+        for d in (16, 32, 96, 128):
+            run(f32, 1, 2, 100, 130, d, causal=True)
+        open(os.path.join(OUT, "diag_f32.txt"), "w").write("\n".join(lines) + "\n")
+        return
     # single 32x32 block, then one tile, then multi-tile; forward only first
     run(bf, 1, 1, 32, 32, 64, grads=False, v_mode="ones")
     run(bf, 1, 1, 32, 32, 64, grads=False, v_mode="onehot")
