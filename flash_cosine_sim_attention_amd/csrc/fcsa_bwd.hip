@@ -32,11 +32,15 @@ template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
                       f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
-                      int i, int j0, int diff, const char* bias_row, float* dbias_row) {
+                      uint32_t ncm, int i, int j0, int diff, const char* bias_row, float* dbias_row) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
+    // branch-free and before the MFMA chains on purpose (see fwd_tile)
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED)
+      w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -44,12 +48,6 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(vt, 32 * jb, kk), dof[kk], dp);
-
-    uint32_t w = 0xffffffffu;
-    if constexpr (MASKED) {
-      w = (uint32_t)(word >> (32 * jb)) >> (4 * fa.hi);
-      if (p.causal) w &= le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi));
-    }
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
     if constexpr (BIAS) {
@@ -102,6 +100,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
   const int mw = m0 + wave * 32;
   const int i = mw + (lane & 31);
   const int diff = p.M - p.N;
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
 
   int last_key = p.M - 1;
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
@@ -181,9 +180,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
     const bool skip = p.causal && (j0 > mw + 31 + diff);
     const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
     if (!skip) {
-      if (has_bias)    dq_tile<T, D, true, true>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
-      else if (masked) dq_tile<T, D, true, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
-      else             dq_tile<T, D, false, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, i, j0, diff, bias_row, dbias_row);
+      if (has_bias)    dq_tile<T, D, true, true>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
+      else if (masked) dq_tile<T, D, true, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
+      else             dq_tile<T, D, false, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
     }
     if (more) {
       sk.store(knxt, tid);
@@ -205,10 +204,14 @@ template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                       const BwdParams& p, bool key_ok, int j, int i0, int diff, int nib, const char* bias_col) {
+                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, int nib, const char* bias_col) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   for (int ib = 0; ib < nib; ++ib) {
+    // query i of register r: i0 + 32*ib + crow(r, hi); valid iff i + diff >= j.
+    // Branch-free and before the MFMA chains on purpose (see fwd_tile).
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -216,13 +219,6 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), vf[kk], dp);
-
-    // query i of register r: i0 + 32*ib + crow(r, hi)
-    uint32_t w = 0xffffffffu;
-    if constexpr (MASKED) {
-      w = key_ok ? 0xffffffffu : 0u;
-      if (p.causal) w &= ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi));   // valid iff i + diff >= j
-    }
     f32x16 pr;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
@@ -303,6 +299,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
   }
   bool key_ok = j < p.M;
   if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
+  const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
 
   f32x16 dk[G::DB], dv[G::DB];
 #pragma unroll
@@ -360,9 +358,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
     if (!skip) {
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
-      if (has_bias)    dkv_tile<T, D, true, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
-      else if (masked) dkv_tile<T, D, true, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
-      else             dkv_tile<T, D, false, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, key_ok, j, i0, diff, nib, bias_col);
+      if (has_bias)    dkv_tile<T, D, true, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nib, bias_col);
+      else if (masked) dkv_tile<T, D, true, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nib, bias_col);
+      else             dkv_tile<T, D, false, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nib, bias_col);
     }
     if (more) store_tile(nxt);
     __syncthreads();

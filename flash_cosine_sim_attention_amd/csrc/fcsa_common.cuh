@@ -66,6 +66,7 @@ template <> struct Traits<BF16> {
   }
   static FCSA_DEV float lo(uint32_t u) { return as_f32(u << 16); }
   static FCSA_DEV float hi(uint32_t u) { return as_f32(u & 0xffff0000u); }
+  static constexpr uint32_t kOne2 = 0x3f803f80u;     // two packed 1.0
 };
 
 template <> struct Traits<F16> {
@@ -80,6 +81,7 @@ template <> struct Traits<F16> {
   }
   static FCSA_DEV float lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
   static FCSA_DEV float hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+  static constexpr uint32_t kOne2 = 0x3c003c00u;     // two packed 1.0
 };
 
 template <> struct Traits<F32> {

@@ -14,7 +14,10 @@
 //   * exp2 + masking + row-sum stay in registers; P~ is packed to 16 bit in place and becomes the
 //     B operand of O^T = V^T P~^T, whose A operand V^T comes from the row-major LDS V tile through
 //     ds_read_b64_tr_b16 (no P~ round trip through shared memory, cf. cu:1222);
-//   * the row sum is a per-lane f32 accumulation of the UN-rounded P~ plus one lane^32 add;
+//   * 16-bit types: the row sum comes from the MATRIX pipe -- one extra MFMA per 16-key step with an
+//     all-ones A operand accumulates sum_j P~[j][i] of exactly the rounded P~ that feeds P~V, so O is
+//     a true convex combination of V rows (the reference also sums the rounded tile, cu:1236) and the
+//     VALU, the busier pipe here, loses 32 adds per tile; f32: per-lane adds plus one lane^32 add;
 //   * float32 inputs run the same skeleton on v_mfma_f32_32x32x2_f32 (exact f32, 1/16 of the bf16
 //     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read.
 #include "fcsa_common.cuh"
@@ -25,22 +28,23 @@ namespace fcsa {
 template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
-                       float& l, const FwdParams& p, uint64_t word, int i, int j0, int diff, const char* bias_row) {
+                       float& l, f32x16& lacc, const FwdParams& p, uint64_t word, uint32_t ncm, int i, int j0, int diff,
+                       const char* bias_row) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
+    // validity bits of this lane's 16 keys.  Branch-free and BEFORE the MFMA chain on purpose: a runtime
+    // branch between the last MFMA and the first read of its result gets too few wait states on the
+    // taken path (hipcc 7.2 pads only the fall-through; seen with the 16-pass v_mfma_f32_32x32x2_f32).
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED)
+      w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
-
-    uint32_t w = 0xffffffffu;
-    if constexpr (MASKED) {
-      w = (uint32_t)(word >> (32 * jb)) >> (4 * fa.hi);
-      if (p.causal) w &= le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi));
-    }
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
     if constexpr (BIAS) {
@@ -58,11 +62,16 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       if constexpr (BIAS) x += bv[r];
       float e = fast_exp2(x);
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
-      l += e;
+      if constexpr (TR::ES == 4) l += e;
       s[r] = e;
     }
     SecondB<T> pb;
     pb.prep(s);
+    if constexpr (TR::ES == 2) {      // lacc[*][i] += sum over this block's 32 keys of the rounded P~
+      const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
+      lacc = TR::mfma32(ones, pb.v[0], lacc);
+      lacc = TR::mfma32(ones, pb.v[1], lacc);
+    }
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
   }
@@ -91,6 +100,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const int mw = m0 + wave * 32;                  // first query row of this wave
   const int i = mw + (lane & 31);                 // this lane's query row
   const int diff = p.M - p.N;                     // cu:1097 seq_len_diff
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
 
   // key tiles this workgroup needs
   int last_key = p.M - 1;
@@ -114,7 +124,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   for (int db = 0; db < G::DB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float l = 0.f;
+  float l = 0.f;          // f32: per-lane partial row sum
+  f32x16 lacc;            // 16 bit: row sums from the ones-MFMA (every register holds the full sum of column i)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
 
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
@@ -153,9 +166,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
     const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
     if (!skip) {
-      if (has_bias)    fwd_tile<T, D, true, true>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
-      else if (masked) fwd_tile<T, D, true, false>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
-      else             fwd_tile<T, D, false, false>(kcur, vcur, fa, qf, o, l, p, word, i, j0, diff, bias_row);
+      if (has_bias)    fwd_tile<T, D, true, true>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
+      else if (masked) fwd_tile<T, D, true, false>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
+      else             fwd_tile<T, D, false, false>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
     }
     if (more) {
       sk.store(knxt, tid);
@@ -165,7 +178,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   }
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
-  const float lt = xhalf_sum(l);
+  const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
   const float inv = 1.f / fmaxf(lt, 1e-10f);      // cu:1239 (constants::eps, cu:83)
   if (i < p.N) {
     if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = inv;
