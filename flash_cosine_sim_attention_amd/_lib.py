@@ -13,7 +13,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcsa_hip.so")
+# FCSA_LIB selects an alternative build of the same ABI (kernel-tuning A/B runs, tools/ab_bench.py)
+LIB_PATH = os.environ.get("FCSA_LIB") or os.path.join(_HERE, "libfcsa_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 FCSA_F32, FCSA_F16, FCSA_BF16 = 0, 1, 2

@@ -20,6 +20,18 @@
 //
 // 7 tile products instead of the reference's 5 (S and dP are recomputed in both kernels); results
 // are deterministic.  d_bias (optional path) is accumulated with f32 atomics like cu:1574-1576.
+// As in the forward kernel, each kernel runs its unmasked tiles and its masked tiles in two
+// sequential loops with one straight-line body each (no accumulator copies at if/else joins).
+#include <type_traits>
+
+// tuning knobs (row bytes D*ES up to which a kernel asks for 2 waves/SIMD, i.e. <= 256 registers)
+#ifndef FCSA_DKV_2W_BYTES
+#define FCSA_DKV_2W_BYTES 64
+#endif
+#ifndef FCSA_DQ_2W_BYTES
+#define FCSA_DQ_2W_BYTES 128
+#endif
+
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
 
@@ -48,6 +60,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(vt, 32 * jb, kk), dof[kk], dp);
+
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
     if constexpr (BIAS) {
@@ -77,8 +90,8 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
   }
 }
 
-template <typename T, int D, int NW>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+template <typename T, int D, int NW, bool BIAS>
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
@@ -142,10 +155,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
-  const bool has_bias = p.bias != nullptr;        // wave-uniform (kernel argument)
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   float* dbias_row = nullptr;                     // only for real rows
-  if (has_bias) {
+  if constexpr (BIAS) {
     const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M;
     bias_row = p.bias + boff * (int64_t)sizeof(typename TR::elem);
     if (p.d_bias != nullptr && i < p.N) dbias_row = p.d_bias + boff;
@@ -162,34 +174,45 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
   }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const int j0 = t * BN;
-    const char* kcur = smem + (t & 1) * 2 * TILE_B;
-    const char* vcur = kcur + TILE_B;
-    char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
-    const bool more = t + 1 < nt;
-    if (more) {
-      sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
-      sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
-    }
-    const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);
-    if (mrow && more) {
-      const int key = j0 + BN + lane;
-      mb = key < p.M ? mrow[key] : (uint8_t)0;
-    }
-    const bool skip = p.causal && (j0 > mw + 31 + diff);
-    const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
-    if (!skip) {
-      if (has_bias)    dq_tile<T, D, true, true>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
-      else if (masked) dq_tile<T, D, true, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
-      else             dq_tile<T, D, false, false>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
-    }
-    if (more) {
-      sk.store(knxt, tid);
-      sv.store(knxt + TILE_B, tid);
-    }
-    __syncthreads();
+  int t_split = 0;                                 // see fwd_kernel
+  if (!BIAS && mrow == nullptr) {
+    t_split = p.M / BN;
+    if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);
+    t_split = min(t_split, nt);
   }
+
+  auto run = [&](auto masked_tag, int t_begin, int t_end) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    for (int t = t_begin; t < t_end; ++t) {
+      const int j0 = t * BN;
+      const char* kcur = smem + (t & 1) * 2 * TILE_B;
+      const char* vcur = kcur + TILE_B;
+      char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+      const bool more = t + 1 < nt;
+      if (more) {
+        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
+        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
+      }
+      if constexpr (MASKED) {
+        const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);
+        if (mrow && more) {
+          const int key = j0 + BN + lane;
+          mb = key < p.M ? mrow[key] : (uint8_t)0;
+        }
+        const bool skip = p.causal && (j0 > mw + 31 + diff);
+        if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
+      } else {
+        dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, dbias_row);
+      }
+      if (more) {
+        sk.store(knxt, tid);
+        sv.store(knxt + TILE_B, tid);
+      }
+      __syncthreads();
+    }
+  };
+  run(std::false_type{}, 0, t_split);
+  run(std::true_type{}, t_split, nt);
 
   if (i < p.N) {
     char* row = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)i * p.dq.sn;
@@ -200,15 +223,17 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) b
 // =============================================================================================
 // dK / dV kernel
 // =============================================================================================
-template <typename T, int D, bool MASKED, bool BIAS>
+template <typename T, int D, int BMQ, bool MASKED, bool BIAS>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, int nib, const char* bias_col) {
+                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  for (int ib = 0; ib < nib; ++ib) {
-    // query i of register r: i0 + 32*ib + crow(r, hi); valid iff i + diff >= j.
+#pragma unroll
+  for (int ib = 0; ib < BMQ / 32; ++ib) {
+    // query i of register r: i0 + 32*ib + crow(r, hi); valid iff i + diff >= j.  Rows >= N carry
+    // lc = -inf (P = 0) and zero Q / dO, so whole blocks beyond N contribute exactly nothing.
     // Branch-free and before the MFMA chains on purpose (see fwd_tile).
     uint32_t w = 0xffffffffu;
     if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
@@ -219,6 +244,7 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), vf[kk], dp);
+
     f32x16 pr;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
@@ -251,8 +277,8 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
   }
 }
 
-template <typename T, int D, int NW, int BMQ>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+template <typename T, int D, int NW, int BMQ, bool BIAS>
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYTES ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
@@ -312,9 +338,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
   const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
-  const bool has_bias = p.bias != nullptr;        // wave-uniform (kernel argument)
   const char* bias_col = nullptr;                 // column min(j, M-1): always a valid address
-  if (has_bias)
+  if constexpr (BIAS)
     bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
 
   Stager<T, D, BMQ, NT> sq, sdo;
@@ -345,26 +370,37 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
   }
   __syncthreads();
 
-  for (int t = t0; t < QT; ++t) {
-    const int i0 = t * BMQ;
-    const int par = (t - t0) & 1;
-    const char* cur = smem + par * BUF_B;
-    char* nxt = smem + (par ^ 1) * BUF_B;
-    const bool more = t + 1 < QT;
-    if (more) load_tile(t + 1);
-    const int nib = min(BMQ, p.N - i0 + 31) / 32;                       // 32-row blocks that contain real rows
-    const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
-    const bool masked = (p.mask != nullptr) || (n0 + BNK > p.M) || (p.causal && (i0 + diff < nw + 31));
-    if (!skip) {
+  // query tiles [t0, t_m) need masking for THIS wave (key mask / invalid keys: all of them; causal: the tiles
+  // that touch the diagonal, i0 + diff < nw + 31), tiles [t_m, QT) do not.  Wave-uniform split.
+  int t_m = QT;
+  if (!BIAS && p.mask == nullptr && n0 + BNK <= p.M) {
+    t_m = t0;
+    if (p.causal) t_m = min(QT, max(t0, (nw + 31 - diff + BMQ - 1) / BMQ));
+  }
+
+  auto run = [&](auto masked_tag, int t_begin, int t_end) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    for (int t = t_begin; t < t_end; ++t) {
+      const int i0 = t * BMQ;
+      const int par = (t - t0) & 1;
+      const char* cur = smem + par * BUF_B;
+      char* nxt = smem + (par ^ 1) * BUF_B;
+      const bool more = t + 1 < QT;
+      if (more) load_tile(t + 1);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
-      if (has_bias)    dkv_tile<T, D, true, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nib, bias_col);
-      else if (masked) dkv_tile<T, D, true, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nib, bias_col);
-      else             dkv_tile<T, D, false, false>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nib, bias_col);
+      if constexpr (MASKED) {
+        const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
+        if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col);
+      } else {
+        dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col);
+      }
+      if (more) store_tile(nxt);
+      __syncthreads();
     }
-    if (more) store_tile(nxt);
-    __syncthreads();
-  }
+  };
+  run(std::true_type{}, t0, t_m);
+  run(std::false_type{}, t_m, QT);
 
   if (j < p.M) {
     char* dkrow = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)j * p.dk.sn;
@@ -375,29 +411,44 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 64 ? 2 : 1)) bw
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D>
-static hipError_t launch_dq_t(const BwdParams& p, hipStream_t s) {
+template <typename K>
+static hipError_t set_lds_once(K kern, size_t lds, bool& done) {
+  if (done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) done = true;
+  return e;
+}
+
+template <typename T, int D, bool BIAS>
+static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   constexpr int NW = 4, BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
-  auto kern = bwd_dq_kernel<T, D, NW>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  auto kern = bwd_dq_kernel<T, D, NW, BIAS>;
+  static bool attr_set = false;
+  if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * MT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 
-template <typename T, int D>
-static hipError_t launch_dkv_t(const BwdParams& p, hipStream_t s) {
+template <typename T, int D, bool BIAS>
+static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   constexpr int NW = 4, BNK = 32 * NW;
   constexpr int BMQ = (Traits<T>::ES == 4 && D >= 96) ? 32 : 64;   // f32 at D >= 96: halve the staged tile (VGPR budget)
   const int KT = (p.M + BNK - 1) / BNK;
   const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);
-  auto kern = bwd_dkv_kernel<T, D, NW, BMQ>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
+  static bool attr_set = false;
+  if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * KT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
+}
+
+template <typename T, int D> static hipError_t launch_dq_t(const BwdParams& p, hipStream_t s) {
+  return p.bias != nullptr ? launch_dq_b<T, D, true>(p, s) : launch_dq_b<T, D, false>(p, s);
+}
+template <typename T, int D> static hipError_t launch_dkv_t(const BwdParams& p, hipStream_t s) {
+  return p.bias != nullptr ? launch_dkv_b<T, D, true>(p, s) : launch_dkv_b<T, D, false>(p, s);
 }
 
 #define FCSA_DISPATCH_D(FN, T)                      \

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -81,17 +82,29 @@ fcsa::View contiguous_view(void* p, int64_t heads, int64_t len, int64_t d, int e
   return v;
 }
 
-// exponent shift (in natural-log units).  The reference always uses `scale` (cu:1216), which bounds the
-// exponent by 0 for groups == 1.  With groups = g the logit reaches scale*g; in f16 the un-normalised
-// P~ = exp(s - shift) must stay below 65504 ~ e^11, so the shift is raised just enough.  Any shift
-// gives the same O; only the saved inv_l carries it, and forward/backward derive it identically.
+// Exponent shift (natural-log units): P~ = exp(s - shift).  Any shift gives the same O; only the saved
+// inv_l carries it, and forward / backward derive it identically from the problem description.
+//   * l2norm_qk == 0 (the reference extension's contract, q,k pre-normalised by the caller): shift = scale,
+//     exactly cu:1216, so inv_l has the reference's values.
+//   * fused l2norm: the logit is bounded by scale * groups.
+//       f16 : shift = scale*groups - 10  ->  P~ <= e^10 = 22026 < 65504, and typical P~ (logit ~ 0) stays in
+//             f16's NORMAL range even for large scale (with the reference's shift, scale = 16 puts exp(-16)
+//             = 1e-7 into f16 subnormals and the output error grows 10x).
+//       bf16 / f32 (8-bit exponent): shift = max(scale, scale*groups - 40); equals the reference for groups = 1.
 float exponent_shift(const fcsa_problem& p) {
-  float shift = p.scale;
-  if (p.dtype == FCSA_F16 && p.l2norm_qk && p.groups > 1) {
-    const float lim = p.scale * (float)p.groups - 10.f;
-    if (lim > shift) shift = lim;
-  }
-  return shift;
+  if (!p.l2norm_qk) return p.scale;
+  const float bound = p.scale * (float)p.groups;
+  if (p.dtype == FCSA_F16) return bound - 10.f;
+  return bound - 40.f > p.scale ? bound - 40.f : p.scale;
+}
+
+// Row-sum clamp: the reference clamps l at 1e-10 (cu:83, cu:1239) with shift = scale; with another shift the
+// same clamp in the reference's units is 1e-10 * exp(scale - shift) (kept inside f32's normal range).
+float rowsum_eps(const fcsa_problem& p) {
+  float e = 1e-10f * expf(p.scale - exponent_shift(p));
+  if (!(e > 1e-37f)) e = 1e-37f;
+  if (e > 1e30f) e = 1e30f;
+  return e;
 }
 
 struct BwdLayout {
@@ -255,6 +268,7 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.c1 = p.scale * kLog2e;
   fp.c2 = exponent_shift(p) * kLog2e;
   fp.bias_c = kLog2e;
+  fp.l_eps = rowsum_eps(p);
   return timed("fwd", "forward", s, [&] { return fcsa::launch_forward(p.dtype, p.dim_head, fp, s); });
 }
 

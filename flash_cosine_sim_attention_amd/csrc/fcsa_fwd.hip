@@ -2,7 +2,7 @@
 //
 // Replaces forward_kernel (reference cu:1072-1247).  Math (cu:1204-1246):
 //     S = scale * Qh Kh^T (+ bias);  P~ = valid ? exp(S - shift) : 0;  l = rowsum(P~);
-//     O = (P~ V) / max(l, 1e-10);    inv_l = 1 / max(l, 1e-10)
+//     O = (P~ V) / max(l, eps);      inv_l = 1 / max(l, eps)
 // with NO running max / rescale (logits are bounded because q, k are l2-normalised).
 //
 // Decomposition (one workgroup = NW waves = 32*NW query rows; K/V tiles of BN = 64 keys):
@@ -11,7 +11,7 @@
 //   * K and V tiles are staged global -> VGPR -> LDS, double buffered, one barrier per tile;
 //   * S^T = K Q^T on v_mfma_f32_32x32x16 (A = K rows via ds_read_b128, B = Q registers), so a
 //     lane owns ONE query (column) and 16 keys (rows) of each 32x32 block;
-//   * exp2 + masking + row-sum stay in registers; P~ is packed to 16 bit in place and becomes the
+//   * exp2 + masking stay in registers; P~ is packed to 16 bit in place and becomes the
 //     B operand of O^T = V^T P~^T, whose A operand V^T comes from the row-major LDS V tile through
 //     ds_read_b64_tr_b16 (no P~ round trip through shared memory, cf. cu:1222);
 //   * 16-bit types: the row sum comes from the MATRIX pipe -- one extra MFMA per 16-key step with an
@@ -19,7 +19,12 @@
 //     a true convex combination of V rows (the reference also sums the rounded tile, cu:1236) and the
 //     VALU, the busier pipe here, loses 32 adds per tile; f32: per-lane adds plus one lane^32 add;
 //   * float32 inputs run the same skeleton on v_mfma_f32_32x32x2_f32 (exact f32, 1/16 of the bf16
-//     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read.
+//     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read;
+//   * the key loop is split in two SEQUENTIAL loops, first the tiles that need no masking, then the
+//     tiles that do (key mask / tail / causal diagonal).  Each loop has one straight-line body, so the
+//     accumulators never cross an if/else join (which costs dozens of register copies per tile).
+#include <type_traits>
+
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
 
@@ -45,6 +50,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
+
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
     if constexpr (BIAS) {
@@ -77,7 +83,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
   }
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool BIAS>
 __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) fwd_kernel(const FwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -107,7 +113,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
-  // Q fragments (B operand of S^T = K Q^T): features 16*kk + 8*hi .. +8 of row i
+  // Q fragments (B operand of S^T = K Q^T): 16-byte chunk 2*kk + hi of row i
   u32x4 qf[G::KS];
   {
     const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
@@ -132,9 +138,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
-  const bool has_bias = p.bias != nullptr;        // wave-uniform (kernel argument)
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
-  if (has_bias)
+  if constexpr (BIAS)
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
 
   Stager<T, D, BN, NT> sk, sv;
@@ -148,38 +153,51 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const int j0 = t * BN;
-    const char* kcur = smem + (t & 1) * 2 * TILE_B;
-    const char* vcur = kcur + TILE_B;
-    char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
-    const bool more = t + 1 < nt;
-    if (more) {   // issue next tile's global loads now; they land while this tile is computed
-      sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
-      sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
-    }
-    const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);   // valid keys of this tile
-    if (mrow && more) {
-      const int key = j0 + BN + lane;
-      mb = key < p.M ? mrow[key] : (uint8_t)0;
-    }
-    const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
-    const bool masked = (mrow != nullptr) || (j0 + BN > p.M) || (p.causal && (j0 + BN - 1 > mw + diff));
-    if (!skip) {
-      if (has_bias)    fwd_tile<T, D, true, true>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
-      else if (masked) fwd_tile<T, D, true, false>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
-      else             fwd_tile<T, D, false, false>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
-    }
-    if (more) {
-      sk.store(knxt, tid);
-      sv.store(knxt + TILE_B, tid);
-    }
-    __syncthreads();
+  // tiles [0, t_split) need no masking for THIS wave, tiles [t_split, nt) do (wave-uniform split; both
+  // loops execute one barrier per tile, so waves of one workgroup may sit in different loops)
+  int t_split = 0;
+  if (!BIAS && mrow == nullptr) {
+    t_split = p.M / BN;                                                // tail tile (j0 + BN > M) is masked
+    if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);  // needs (t+1)*BN - 1 <= mw + diff
+    t_split = min(t_split, nt);
   }
+
+  auto run = [&](auto masked_tag, int t_begin, int t_end) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    for (int t = t_begin; t < t_end; ++t) {
+      const int j0 = t * BN;
+      const char* kcur = smem + (t & 1) * 2 * TILE_B;
+      const char* vcur = kcur + TILE_B;
+      char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+      const bool more = t + 1 < nt;
+      if (more) {   // issue next tile's global loads now; they land while this tile is computed
+        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
+        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
+      }
+      if constexpr (MASKED) {
+        const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);   // valid keys of this tile
+        if (mrow && more) {
+          const int key = j0 + BN + lane;
+          mb = key < p.M ? mrow[key] : (uint8_t)0;
+        }
+        const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
+        if (!skip) fwd_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
+      } else {
+        fwd_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, o, l, lacc, p, 0, ncm, i, j0, diff, bias_row);
+      }
+      if (more) {
+        sk.store(knxt, tid);
+        sv.store(knxt + TILE_B, tid);
+      }
+      __syncthreads();
+    }
+  };
+  run(std::false_type{}, 0, t_split);
+  run(std::true_type{}, t_split, nt);
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
   const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
-  const float inv = 1.f / fmaxf(lt, 1e-10f);      // cu:1239 (constants::eps, cu:83)
+  const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift
   if (i < p.N) {
     if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = inv;
     char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
@@ -187,17 +205,26 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   }
 }
 
-template <typename T, int D>
-static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
+template <typename T, int D, bool BIAS>
+static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
-  auto kern = fwd_kernel<T, D, NW>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  auto kern = fwd_kernel<T, D, NW, BIAS>;
+  static bool attr_set = false;                  // per instantiation; the attribute is sticky
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * MT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
+}
+
+template <typename T, int D>
+static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
+  return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);
 }
 
 template <typename T>

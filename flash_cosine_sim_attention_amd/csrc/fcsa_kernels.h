@@ -21,6 +21,7 @@ struct FwdParams {
   float c1;                 // scale * log2(e)
   float c2;                 // shift * log2(e)      (P~ = exp2(c1 * qk - c2))
   float bias_c;             // log2(e)              (bias enters as bias * log2e)
+  float l_eps;              // clamp of the row sum: 1e-10 (cu:83) rescaled by exp(scale - shift)
 };
 
 struct BwdParams {
