@@ -26,7 +26,7 @@
 
 // tuning knobs (row bytes D*ES up to which a kernel asks for 2 waves/SIMD, i.e. <= 256 registers)
 #ifndef FCSA_DKV_2W_BYTES
-#define FCSA_DKV_2W_BYTES 64
+#define FCSA_DKV_2W_BYTES 128
 #endif
 #ifndef FCSA_DQ_2W_BYTES
 #define FCSA_DQ_2W_BYTES 128

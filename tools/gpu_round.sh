@@ -14,3 +14,14 @@ find gpurun_out/prof_stats -name "*kernel_stats*" | head -3
 f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f"
 # keep the merged-back payload small
 find gpurun_out/prof_stats -name "*kernel_trace.csv" -size +20M -delete
+# copy the judged artefacts out of the sqlite/trace clutter
+python - <<'PY'
+import glob, os, sqlite3, csv
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+dbs = glob.glob(os.path.join(root, "gpurun_out/prof_stats/**/*.db"), recursive=True)
+out = os.path.join(root, "gpurun_out/kernel_stats.csv")
+if dbs:
+    con = sqlite3.connect(dbs[0]); cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    print("tables:", [t for t in tabs if "kernel" in t.lower()][:12])
+PY
