@@ -43,6 +43,18 @@ def flops(w, fwd=True, bwd=True):
     return f * (causal_fraction(w["N"], w["M"]) if w["causal"] else 1.0)
 
 
+def aggregate_over_ranks(elapsed_s, flops_local, dist=None, device="cpu"):
+    """Whole-job figures from per-rank ones: time = MAX over ranks, work = SUM over ranks (replicas, no data-path
+    collective).  Returns (elapsed_max_s, flops_total).  `dist` is torch.distributed (initialised) or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed_s), float(flops_local)
+    t = torch.tensor([elapsed_s], device=device, dtype=torch.float64)
+    f = torch.tensor([flops_local], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(f.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,13 +107,9 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, flops_per_step_all_ranks = aggregate_over_ranks(elapsed, flops(w), dist, "cuda")
     ms_per_step = elapsed / args.steps * 1e3
-    total_flops = flops(w) * world
-    value = total_flops / (ms_per_step * 1e-3) / 1e12
+    value = flops_per_step_all_ranks / (ms_per_step * 1e-3) / 1e12
 
     # ---- roofline: dominant kernel, timed with HIP events on the launch stream (library hook) ----------
     roofline = None

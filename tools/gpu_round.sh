@@ -8,20 +8,9 @@ echo "== diag =="; timeout 600 python tools/gpu_diag.py > gpurun_out/diag.log 2>
 echo "== pytest gpu =="; timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; tail -n 40 gpurun_out/pytest_gpu.log
 echo "== bench =="; timeout 600 python bench.py > gpurun_out/bench.log 2>&1; tail -n 3 gpurun_out/bench.log
 echo "== rocprofv3 kernel stats =="
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_stats" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events > "$GRAFT_REPO_ROOT/gpurun_out/rocprof_stats.log" 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_stats" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events > "$GRAFT_REPO_ROOT/gpurun_out/rocprof_stats.log" 2>&1 )
 tail -n 5 gpurun_out/rocprof_stats.log
 find gpurun_out/prof_stats -name "*kernel_stats*" | head -3
-f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f"
+f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cp "$f" gpurun_out/kernel_stats.csv; head -n 12 "$f" | cut -c1-250; }
 # keep the merged-back payload small
 find gpurun_out/prof_stats -name "*kernel_trace.csv" -size +20M -delete
-# copy the judged artefacts out of the sqlite/trace clutter
-python - <<'PY'
-import glob, os, sqlite3, csv
-root = os.environ.get("GRAFT_REPO_ROOT", ".")
-dbs = glob.glob(os.path.join(root, "gpurun_out/prof_stats/**/*.db"), recursive=True)
-out = os.path.join(root, "gpurun_out/kernel_stats.csv")
-if dbs:
-    con = sqlite3.connect(dbs[0]); cur = con.cursor()
-    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-    print("tables:", [t for t in tabs if "kernel" in t.lower()][:12])
-PY
