@@ -164,15 +164,22 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   }
 
   Stager<T, D, BN, NT> sk, sv;
+  sk.init(p.k.sn, tid);
+  sv.init(p.v.sn, tid);
   uint8_t mb = 1;
   if (nt > 0) {
-    sk.load(kbase, p.k.sn, p.M, tid);
-    sv.load(vbase, p.v.sn, p.M, tid);
+    sk.load(kbase, p.k.sn, p.M);
+    sv.load(vbase, p.v.sn, p.M);
     if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
     sk.store(smem, tid);
     sv.store(smem + TILE_B, tid);
   }
   __syncthreads();
+  // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
+  // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never
+  // clears that, and each iteration re-waits with vmcnt(0) at its first MFMA -- right after issuing the next
+  // tile's prefetch, which serialises the prefetch with the compute meant to hide it.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
   int t_split = 0;                                 // see fwd_kernel
   if (!BIAS && mrow == nullptr) {
@@ -190,8 +197,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
       const bool more = t + 1 < nt;
       if (more) {
-        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
-        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
+        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN));
+        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN));
       }
       if constexpr (MASKED) {
         const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);
@@ -343,11 +350,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
 
   Stager<T, D, BMQ, NT> sq, sdo;
+  sq.init(p.q.sn, tid);
+  sdo.init(p.d_out.sn, tid);
   float lc_r = 0.f, dl_r = 0.f;
   auto load_tile = [&](int t) {
     const int i0 = t * BMQ;
-    sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0, tid);
-    sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0, tid);
+    sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0);
+    sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
     if (tid < BMQ) {
       const int i = i0 + tid;
       // rows beyond N: lc = -inf makes P exactly 0 there
@@ -369,6 +378,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     store_tile(smem);
   }
   __syncthreads();
+  // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
+  // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never
+  // clears that, and each iteration re-waits with vmcnt(0) at its first MFMA -- right after issuing the next
+  // tile's prefetch, which serialises the prefetch with the compute meant to hide it.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
   // query tiles [t0, t_m) need masking for THIS wave (key mask / invalid keys: all of them; causal: the tiles
   // that touch the diagonal, i0 + diff < nw + 31), tiles [t_m, QT) do not.  Wave-uniform split.

@@ -236,25 +236,40 @@ FCSA_DEV f32x16 second_mma(f32x16 acc, const char* tile, int rbase, int db, cons
 
 // ---------------------------------------------------------------------------------------------
 // global -> registers -> LDS staging of a [ROWS][D] tile by NT threads (split issue / write, so the
-// HBM/L2 latency hides under the MFMA phase in between: guide T14)
+// HBM/L2 latency hides under the MFMA phase in between: guide T14).
+//
+// Loads are buffer loads (guide T8): a 128-bit descriptor in SGPRs rebuilt per tile on the scalar unit
+// (base = first row of the tile, num_records = bytes that remain in the tensor slice) plus a per-lane
+// byte offset that is computed ONCE and stays live.  Two reasons:
+//   * with flat/global loads the address VGPR pair is recomputed per tile and then recycled; hipcc guards
+//     that write-after-read with s_waitcnt vmcnt(0) right before the first MFMA of the tile, i.e. the
+//     prefetch it was meant to overlap is waited for immediately (seen in the ISA, ~1/3 of wave cycles);
+//   * the hardware range check returns zeros past num_records, which is exactly the zero fill needed for
+//     rows beyond the end of the sequence -- no predication, no clamping.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D, int ROWS, int NT> struct Stager {
   typedef TileGeom<D, Traits<T>::ES> G;
   static constexpr int NCH = ROWS * G::CPR;
   static constexpr int PER = (NCH + NT - 1) / NT;
+  static constexpr int ROW_BYTES = D * Traits<T>::ES;
   u32x4 r[PER];
+  int voff[PER];       // loop-invariant byte offset of this lane's chunk i inside a tile
 
-  // g: address of (row 0, feature 0) of the tile; pitch in bytes; rows >= rows_valid read as zero
-  FCSA_DEV void load(const char* g, int64_t pitch, int rows_valid, int tid) {
+  FCSA_DEV void init(int64_t pitch, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int c = tid + i * NT;
       const int row = c / G::CPR, ch = c % G::CPR;
-      u32x4 z = {0u, 0u, 0u, 0u};
-      r[i] = z;
-      if ((NCH % NT == 0 || c < NCH) && row < rows_valid)
-        r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * pitch + ch * 16);
+      voff[i] = (NCH % NT == 0 || c < NCH) ? (int)(row * pitch + ch * 16) : 0x7ffffff0;   // beyond any num_records
     }
+  }
+  // g: address of (row 0, feature 0) of the tile (wave-uniform); rows >= rows_valid read as zero
+  FCSA_DEV void load(const char* g, int64_t pitch, int rows_valid) {
+    int64_t bytes = rows_valid > 0 ? (int64_t)(rows_valid - 1) * pitch + ROW_BYTES : 0;
+    if (bytes > 0x7fffffff) bytes = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, (int)bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], 0, 0);
   }
   FCSA_DEV void store(char* tile, int tid) const {
 #pragma unroll

@@ -143,15 +143,22 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
 
   Stager<T, D, BN, NT> sk, sv;
+  sk.init(p.k.sn, tid);
+  sv.init(p.v.sn, tid);
   uint8_t mb = 1;
   if (nt > 0) {
-    sk.load(kbase, p.k.sn, p.M, tid);
-    sv.load(vbase, p.v.sn, p.M, tid);
+    sk.load(kbase, p.k.sn, p.M);
+    sv.load(vbase, p.v.sn, p.M);
     if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
     sk.store(smem, tid);
     sv.store(smem + TILE_B, tid);
   }
   __syncthreads();
+  // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
+  // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never
+  // clears that, and each iteration re-waits with vmcnt(0) at its first MFMA -- right after issuing the next
+  // tile's prefetch, which serialises the prefetch with the compute meant to hide it.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
   // tiles [0, t_split) need no masking for THIS wave, tiles [t_split, nt) do (wave-uniform split; both
   // loops execute one barrier per tile, so waves of one workgroup may sit in different loops)
@@ -171,8 +178,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
       const bool more = t + 1 < nt;
       if (more) {   // issue next tile's global loads now; they land while this tile is computed
-        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN), tid);
-        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN), tid);
+        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN));
+        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN));
       }
       if constexpr (MASKED) {
         const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);   // valid keys of this tile
