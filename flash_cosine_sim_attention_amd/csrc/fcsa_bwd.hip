@@ -196,16 +196,19 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       const char* vcur = kcur + TILE_B;
       char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
       const bool more = t + 1 < nt;
+      uint64_t word = 0;
+      if constexpr (MASKED) {     // consume the mask byte BEFORE issuing new loads (see fwd_kernel)
+        word = __ballot((j0 + lane) < p.M && mb != 0);
+        if (mrow && more) {
+          const int key = j0 + BN + lane;
+          mb = key < p.M ? mrow[key] : (uint8_t)0;
+        }
+      }
       if (more) {
         sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN));
         sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN));
       }
       if constexpr (MASKED) {
-        const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);
-        if (mrow && more) {
-          const int key = j0 + BN + lane;
-          mb = key < p.M ? mrow[key] : (uint8_t)0;
-        }
         const bool skip = p.causal && (j0 > mw + 31 + diff);
         if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
       } else {
@@ -353,23 +356,25 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   sq.init(p.q.sn, tid);
   sdo.init(p.d_out.sn, tid);
   float lc_r = 0.f, dl_r = 0.f;
+  bool row_ok = false;
   auto load_tile = [&](int t) {
     const int i0 = t * BMQ;
     sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0);
     sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
-    if (tid < BMQ) {
-      const int i = i0 + tid;
-      // rows beyond N: lc = -inf makes P exactly 0 there
-      lc_r = i < p.N ? __builtin_amdgcn_logf(invl_row[i]) - p.c2 : -INFINITY;
-      dl_r = i < p.N ? delta_row[i] : 0.f;
+    if (tid < BMQ) {       // raw loads only: any arithmetic on them here would force an immediate vmcnt wait
+      const int i = min(i0 + tid, p.N - 1);
+      lc_r = invl_row[i];
+      dl_r = delta_row[i];
+      row_ok = i0 + tid < p.N;
     }
   };
   auto store_tile = [&](char* buf) {
     sq.store(buf, tid);
     sdo.store(buf + TILE_B, tid);
     if (tid < BMQ) {
-      reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = lc_r;
-      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = dl_r;
+      // rows beyond N: lc = -inf makes P exactly 0 there
+      reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -INFINITY;
+      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? dl_r : 0.f;
     }
   };
 

@@ -177,16 +177,20 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       const char* vcur = kcur + TILE_B;
       char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
       const bool more = t + 1 < nt;
+      uint64_t word = 0;
+      if constexpr (MASKED) {
+        // consume the mask byte loaded one tile ago BEFORE issuing new loads (its wait then covers nothing else)
+        word = __ballot((j0 + lane) < p.M && mb != 0);                  // valid keys of this tile
+        if (mrow && more) {
+          const int key = j0 + BN + lane;
+          mb = key < p.M ? mrow[key] : (uint8_t)0;
+        }
+      }
       if (more) {   // issue next tile's global loads now; they land while this tile is computed
         sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN));
         sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN));
       }
       if constexpr (MASKED) {
-        const uint64_t word = __ballot((j0 + lane) < p.M && mb != 0);   // valid keys of this tile
-        if (mrow && more) {
-          const int key = j0 + BN + lane;
-          mb = key < p.M ? mrow[key] : (uint8_t)0;
-        }
         const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
         if (!skip) fwd_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
       } else {
