@@ -104,16 +104,20 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   FragAddr<T, D> fa;
   fa.init(lane);
 
+  // causal: a workgroup takes the PAIR of row tiles (MT-1-pt, pt) -> constant work per workgroup (see fwd_kernel)
   const int MT = (p.N + BM - 1) / BM;
-  int bh, mt;
-  block_to_work(blockIdx.x, p.B * p.H, MT, bh, mt);
-  if (p.causal) mt = MT - 1 - mt;
+  const int PT = p.causal ? (MT + 1) / 2 : MT;
+  int bh, pt;
+  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
+  const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
+  const int diff = p.M - p.N;
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
+  for (int pass = 0; pass < npass; ++pass) {
+  const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;
   const int i = mw + (lane & 31);
-  const int diff = p.M - p.N;
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
 
   int last_key = p.M - 1;
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
@@ -228,6 +232,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     char* row = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)i * p.dq.sn;
     store_row_tile<T, D>(row, dq, p.scale, fa.hi, p.dq_f32 != 0);     // cu:1580-1582: dS *= scale
   }
+  }   // pass
 }
 
 // =============================================================================================
@@ -303,14 +308,19 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   FragAddr<T, D> fa;
   fa.init(lane);
 
+  // causal: the LOW key tiles are the heavy ones (they see every later query); pair (pt, KT-1-pt) per workgroup
   const int KT = (p.M + BNK - 1) / BNK;
-  int bh, kt;
-  block_to_work(blockIdx.x, p.B * p.H, KT, bh, kt);     // causal: low key tiles are the heavy ones and come first
+  const int PT = p.causal ? (KT + 1) / 2 : KT;
+  int bh, pt;
+  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
+  const int npass = (p.causal && (KT - 1 - pt) != pt) ? 2 : 1;
+  const int diff = p.M - p.N;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int kt = p.causal ? (pass == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
   const int n0 = kt * BNK;
   const int nw = n0 + wave * 32;                        // first key of this wave
   const int j = nw + (lane & 31);                       // this lane's key
-  const int diff = p.M - p.N;
 
   // query tiles this workgroup needs: causal keeps i >= j - diff
   const int QT = (p.N + BMQ - 1) / BMQ;
@@ -427,6 +437,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     store_row_tile<T, D>(dkrow, dk, p.scale, fa.hi, p.dk_f32 != 0);
     store_row_tile<T, D>(dvrow, dv, 1.f, fa.hi, p.dv_f32 != 0);
   }
+  }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,11 +453,12 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   constexpr int NW = 4, BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
+  const int PT = p.causal ? (MT + 1) / 2 : MT;
   const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
   auto kern = bwd_dq_kernel<T, D, NW, BIAS>;
   static bool attr_set = false;
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * MT)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 
@@ -455,11 +467,12 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   constexpr int NW = 4, BNK = 32 * NW;
   constexpr int BMQ = (Traits<T>::ES == 4 && D >= 96) ? 32 : 64;   // f32 at D >= 96: halve the staged tile (VGPR budget)
   const int KT = (p.M + BNK - 1) / BNK;
+  const int PT = p.causal ? (KT + 1) / 2 : KT;
   const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
   static bool attr_set = false;
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * KT)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 

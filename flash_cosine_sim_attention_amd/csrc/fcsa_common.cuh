@@ -304,7 +304,11 @@ FCSA_DEV void store_row_tile(char* row, const f32x16 (&acc)[TileGeom<D, Traits<T
     }
 }
 
+#ifdef FCSA_EXPERIMENT_FAKE_EXP      // timing experiment only (wrong numerics): a full-rate op instead of v_exp_f32
+FCSA_DEV float fast_exp2(float x) { return x * 0.001f; }
+#else
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 // sum of a per-lane value over the two half-waves (lane ^ 32)
 FCSA_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32, 64); }

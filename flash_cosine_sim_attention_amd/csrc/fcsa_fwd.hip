@@ -23,6 +23,7 @@
 //   * the key loop is split in two SEQUENTIAL loops, first the tiles that need no masking, then the
 //     tiles that do (key mask / tail / causal diagonal).  Each loop has one straight-line body, so the
 //     accumulators never cross an if/else join (which costs dozens of register copies per tile).
+#include <cstdlib>
 #include <type_traits>
 
 #include "fcsa_common.cuh"
@@ -30,6 +31,42 @@
 
 namespace fcsa {
 
+// exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
+template <typename T, bool MASKED, bool BIAS>
+FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lacc, const FwdParams& p, uint32_t w,
+                                int jbase, const char* bias_row) {
+  typedef Traits<T> TR;
+  float bv[16];
+  if constexpr (BIAS) {
+    // unconditional loads from clamped (always valid) addresses; out-of-range positions are masked below
+    // or never stored, so their value is irrelevant.  bias_row already points at a valid row.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = min(jbase + crow(r, 0), p.M - 1);
+      bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float x = s[r] * p.c1 - p.c2;
+    if constexpr (BIAS) x += bv[r];
+    float e = fast_exp2(x);
+    if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
+    if constexpr (TR::ES == 4) l += e;
+    s[r] = e;
+  }
+  pb.prep(s);
+  if constexpr (TR::ES == 2) {      // lacc[*][i] += sum over this block's 32 keys of the rounded P~
+    const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
+    lacc = TR::mfma32(ones, pb.v[0], lacc);
+    lacc = TR::mfma32(ones, pb.v[1], lacc);
+  }
+}
+
+// One 64-key tile for one wave.  Software-pipelined on purpose (ablation: the K row-fragment ds_read_b128,
+// when issued just in time in front of their dependent MFMA, were the most expensive item of the tile):
+//   all K fragments of BOTH 32-key blocks are requested first, both S chains are issued back to back, and the
+//   V^T fragments of a block are requested before its exp phase, so LDS latency hides under MFMA / VALU work.
 template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
@@ -37,49 +74,51 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                        const char* bias_row) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  // validity bits of this lane's 16 keys per block.  Branch-free and BEFORE the MFMA chains on purpose: a runtime
+  // branch between the last MFMA and the first read of its result gets too few wait states on the
+  // taken path (hipcc 7.2 pads only the fall-through; seen with the 16-pass v_mfma_f32_32x32x2_f32).
+  uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+  if constexpr (MASKED) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+      w[jb] = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+  }
+  u32x4 kf[2][G::KS];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(kt, 32 * jb, kk);
+  __builtin_amdgcn_sched_barrier(0);     // keep the K requests up here (the scheduler otherwise sinks them next to each MFMA)
+  f32x16 s[2];
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
-    // validity bits of this lane's 16 keys.  Branch-free and BEFORE the MFMA chain on purpose: a runtime
-    // branch between the last MFMA and the first read of its result gets too few wait states on the
-    // taken path (hipcc 7.2 pads only the fall-through; seen with the 16-pass v_mfma_f32_32x32x2_f32).
-    uint32_t w = 0xffffffffu;
-    if constexpr (MASKED)
-      w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
-    f32x16 s;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
-
-    const int jbase = j0 + 32 * jb + 4 * fa.hi;
-    float bv[16];
-    if constexpr (BIAS) {
-      // unconditional loads from clamped (always valid) addresses; out-of-range positions are masked below
-      // or never stored, so their value is irrelevant.  bias_row already points at a valid row.
+    for (int kk = 0; kk < G::KS; ++kk) s[jb] = TR::mfma32(kf[jb][kk], qf[kk], s[jb]);
+  }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = min(jbase + crow(r, 0), p.M - 1);
-        bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float x = s[r] * p.c1 - p.c2;
-      if constexpr (BIAS) x += bv[r];
-      float e = fast_exp2(x);
-      if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
-      if constexpr (TR::ES == 4) l += e;
-      s[r] = e;
-    }
+  for (int jb = 0; jb < 2; ++jb) {
     SecondB<T> pb;
-    pb.prep(s);
-    if constexpr (TR::ES == 2) {      // lacc[*][i] += sum over this block's 32 keys of the rounded P~
-      const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
-      lacc = TR::mfma32(ones, pb.v[0], lacc);
-      lacc = TR::mfma32(ones, pb.v[1], lacc);
-    }
+    if constexpr (TR::ES == 2) {
+      u32x4 vf[G::DB][2];                        // V^T fragments of this block, requested before the exp phase
 #pragma unroll
-    for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
+      for (int db = 0; db < G::DB; ++db) {
+        vf[db][0] = fa.tr_frag(vt, 32 * jb, db);
+        vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // V^T requests stay ahead of the exp phase
+      fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db) {
+        o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
+        o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
+      }
+    } else {
+      fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
+    }
   }
 }
 
@@ -97,16 +136,22 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   FragAddr<T, D> fa;
   fa.init(lane);
 
+  // Work of a row tile grows with its index under causal masking (2 .. 2*MT key tiles), and a workgroup runs
+  // start to finish on one CU, so the makespan would be set by the heaviest tile.  Each workgroup therefore
+  // takes a PAIR of row tiles (MT-1-pt, pt): constant work per workgroup.  Non-causal: one tile each.
   const int MT = (p.N + BM - 1) / BM;
-  int bh, mt;
-  block_to_work(blockIdx.x, p.B * p.H, MT, bh, mt);
-  if (p.causal) mt = MT - 1 - mt;                 // heaviest (longest key range) row tiles first
+  const int PT = p.causal ? (MT + 1) / 2 : MT;
+  int bh, pt;
+  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
+  const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
+  const int diff = p.M - p.N;                     // cu:1097 seq_len_diff
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
+  for (int pass = 0; pass < npass; ++pass) {
+  const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;                  // first query row of this wave
   const int i = mw + (lane & 31);                 // this lane's query row
-  const int diff = p.M - p.N;                     // cu:1097 seq_len_diff
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
 
   // key tiles this workgroup needs
   int last_key = p.M - 1;
@@ -214,6 +259,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
     store_row_tile<T, D>(orow, o, inv, fa.hi, false);
   }
+  }   // pass
 }
 
 template <typename T, int D, bool BIAS>
@@ -221,7 +267,9 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
-  const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
+  const int PT = p.causal ? (MT + 1) / 2 : MT;
+  size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
+  if (const char* pad = getenv("FCSA_EXPERIMENT_LDS_KB")) lds = (size_t)atoi(pad) * 1024;   // occupancy experiments only
   auto kern = fwd_kernel<T, D, NW, BIAS>;
   static bool attr_set = false;                  // per instantiation; the attribute is sticky
   if (!attr_set) {
@@ -229,7 +277,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * MT)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 
