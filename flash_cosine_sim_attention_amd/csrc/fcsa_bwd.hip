@@ -55,7 +55,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
     f32x16 s, dp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = 0.f; }     // lc = log2(inv_l) - c2 rides in as the initial value
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
 #pragma unroll
@@ -72,7 +72,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float x = s[r] * p.c1 + lc;
+      float x = s[r];               // = c1 * qh.kh + lc already (c1 rides on q, lc is the accumulator's initial value)
       if constexpr (BIAS) x += bv[r];
       float e = fast_exp2(x);
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       dof[kk] = z;
       if (i < p.N) {
         qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+        if (!p.q_scaled) qf[kk] = scale_frag<T>(qf[kk], p.c1);
         dof[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
         const u32x4 of = *reinterpret_cast<const u32x4*>(orow + (2 * kk + fa.hi) * 16);
         delta += dot_frag<T>(dof[kk], of);
@@ -252,9 +253,14 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     // Branch-free and before the MFMA chains on purpose (see fwd_tile).
     uint32_t w = 0xffffffffu;
     if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
-    f32x16 s, dp;
+    f32x16 s, dp, dl;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int rq = 0; rq < 4; ++rq) {      // per-query log-normaliser as the accumulator's initial value; delta kept for dS
+      const f32x4 lc4 = *reinterpret_cast<const f32x4*>(lcs + 32 * ib + 8 * rq + 4 * fa.hi);
+      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dls + 32 * ib + 8 * rq + 4 * fa.hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[4 * rq + e] = lc4[e]; dl[4 * rq + e] = dl4[e]; dp[4 * rq + e] = 0.f; }
+    }
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
 #pragma unroll
@@ -262,24 +268,18 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
 
     f32x16 pr;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x4 lc4 = *reinterpret_cast<const f32x4*>(lcs + 32 * ib + 8 * rq + 4 * fa.hi);
-      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dls + 32 * ib + 8 * rq + 4 * fa.hi);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * rq + e;
-        float x = s[r] * p.c1 + lc4[e];
-        if constexpr (BIAS) {   // clamped row: always a valid address; rows >= N have P = 0 through lc = -inf
-          const int i = min(i0 + 32 * ib + crow(r, 0) + 4 * fa.hi, p.N - 1);
-          const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
-              bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
-          x += (float)bv * p.bias_c;
-        }
-        float pe = fast_exp2(x);
-        if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
-        pr[r] = pe;
-        s[r] = pe * (dp[r] - dl4[e]);
+    for (int r = 0; r < 16; ++r) {
+      float x = s[r];                 // = c1 * qh.kh + lc already
+      if constexpr (BIAS) {   // clamped row: always a valid address; rows >= N have P = 0 through lc = -inf
+        const int i = min(i0 + 32 * ib + crow(r, 0) + 4 * fa.hi, p.N - 1);
+        const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
+            bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
+        x += (float)bv * p.bias_c;
       }
+      float pe = fast_exp2(x);
+      if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
+      pr[r] = pe;
+      s[r] = pe * (dp[r] - dl[r]);
     }
     SecondB<T> pp, pd;
     pp.prep(pr);
@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       vf[kk] = z;
       if (j < p.M) {
         kf[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + fa.hi) * 16);
+        if (!p.q_scaled) kf[kk] = scale_frag<T>(kf[kk], p.c1);     // S = Q (c1 K)^T when the Q tile is plain q^
         vf[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + fa.hi) * 16);
       }
     }
@@ -434,7 +435,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   if (j < p.M) {
     char* dkrow = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)j * p.dk.sn;
     char* dvrow = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)j * p.dv.sn;
-    store_row_tile<T, D>(dkrow, dk, p.scale, fa.hi, p.dk_f32 != 0);
+    // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
+    store_row_tile<T, D>(dkrow, dk, p.q_scaled ? p.scale / p.c1 : p.scale, fa.hi, p.dk_f32 != 0);
     store_row_tile<T, D>(dvrow, dv, 1.f, fa.hi, p.dv_f32 != 0);
   }
   }   // pass

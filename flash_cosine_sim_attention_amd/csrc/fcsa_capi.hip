@@ -222,6 +222,7 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
   np.inv_norm = inv_norm;
   np.B = batch; np.H = heads; np.L = len; np.D = dim_head; np.G = groups;
   np.eps = 1e-12f;                                        // F.normalize default (flash_cosine_sim_attention.py:46)
+  np.out_scale = 1.f;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return timed("l2norm", "l2norm", s, [&] { return fcsa::launch_l2norm(dtype, np, s); });
 }
@@ -253,9 +254,11 @@ int fcsa_forward(const fcsa_forward_args* a) {
     np.D = p.dim_head; np.G = p.groups;
     np.x = fp.q; np.xn = static_cast<char*>(n.qn); np.inv_norm = n.rq;
     np.B = p.batch; np.H = p.heads; np.L = p.q_len;
+    np.out_scale = p.scale * kLog2e;       // qn = c1 * q^ (one rounding): the kernels then need no per-logit multiply
     if (int rc = timed("l2norm", "l2norm(q)", s, [&] { return fcsa::launch_l2norm(p.dtype, np, s); })) return rc;
     np.x = view(a->k, es); np.xn = static_cast<char*>(n.kn); np.inv_norm = n.rk;
     np.B = p.batch; np.H = p.kv_heads; np.L = p.k_len;
+    np.out_scale = 1.f;
     if (int rc = timed("l2norm", "l2norm(k)", s, [&] { return fcsa::launch_l2norm(p.dtype, np, s); })) return rc;
     fp.q = contiguous_view(n.qn, p.heads, p.q_len, p.dim_head, es);
     fp.k = contiguous_view(n.kn, p.kv_heads, p.k_len, p.dim_head, es, single);
@@ -269,6 +272,7 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.c2 = exponent_shift(p) * kLog2e;
   fp.bias_c = kLog2e;
   fp.l_eps = rowsum_eps(p);
+  fp.q_scaled = p.l2norm_qk ? 1 : 0;
   return timed("fwd", "forward", s, [&] { return fcsa::launch_forward(p.dtype, p.dim_head, fp, s); });
 }
 
@@ -334,6 +338,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.c2 = exponent_shift(p) * kLog2e;
   bp.bias_c = kLog2e;
   bp.scale = p.scale;
+  bp.q_scaled = p.l2norm_qk ? 1 : 0;
 
   // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
   if (int rc = timed("bwd_dq", "backward dq", s, [&] { return fcsa::launch_backward_dq(p.dtype, p.dim_head, bp, s); })) return rc;
@@ -343,14 +348,17 @@ int fcsa_backward(const fcsa_backward_args* a) {
   nb.eps = 1e-12f;
   nb.D = p.dim_head;
   nb.B = p.batch;
+  nb.xn_scale = 1.f;
   if (L.need_dq_slab) {
     nb.slab = ws + L.dq_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.heads; nb.L = p.q_len;
     nb.xn = static_cast<const char*>(a->norm.qn); nb.inv_norm = a->norm.rq; nb.G = p.groups;
+    nb.xn_scale = 1.f / (p.scale * kLog2e);           // qn holds c1 * q^
     nb.dx = view(a->dq, es);
     if (int rc = timed("finalize", "finalize dq", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
   }
   if (L.need_dk_slab) {
     nb.slab = ws + L.dk_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.kv_heads; nb.L = p.k_len;
+    nb.xn_scale = 1.f;
     if (p.l2norm_qk) { nb.xn = static_cast<const char*>(a->norm.kn); nb.inv_norm = a->norm.rk; nb.G = p.groups; }
     else             { nb.xn = nullptr; nb.inv_norm = nullptr; nb.G = 1; }
     nb.dx = view(a->dk, es);

@@ -112,6 +112,19 @@ template <typename T> FCSA_DEV float dot_frag(const u32x4& a, const u32x4& b) {
   return s;
 }
 
+// multiply the elements of a 16-byte fragment by a scalar (prologue-only work)
+template <typename T> FCSA_DEV u32x4 scale_frag(const u32x4& a, float c) {
+  u32x4 o;
+  if constexpr (Traits<T>::ES == 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(uint32_t, as_f32(a[e]) * c);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = Traits<T>::pack2(Traits<T>::lo(a[e]) * c, Traits<T>::hi(a[e]) * c);
+  }
+  return o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS tile geometry: row-major [rows][D] tile of ES-byte elements, 16-byte chunks XOR-swizzled per
 // row so that

@@ -48,7 +48,7 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float x = s[r] * p.c1 - p.c2;
+    float x = s[r];                 // = c1 * qh.kh - c2 already: c1 rides on q, -c2 is the accumulator's initial value
     if constexpr (BIAS) x += bv[r];
     float e = fast_exp2(x);
     if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
@@ -93,7 +93,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[jb][r] = -p.c2;      // exponent shift as the accumulator's initial value: no per-element fma
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s[jb] = TR::mfma32(kf[jb][kk], qf[kk], s[jb]);
   }
@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       u32x4 z = {0u, 0u, 0u, 0u};
       qf[kk] = z;
       if (i < p.N) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+      if (!p.q_scaled) qf[kk] = scale_frag<T>(qf[kk], p.c1);     // reference-contract path: q^ given, fold c1 here
     }
   }
 

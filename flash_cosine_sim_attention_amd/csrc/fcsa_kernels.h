@@ -22,6 +22,7 @@ struct FwdParams {
   float c2;                 // shift * log2(e)      (P~ = exp2(c1 * qk - c2))
   float bias_c;             // log2(e)              (bias enters as bias * log2e)
   float l_eps;              // clamp of the row sum: 1e-10 (cu:83) rescaled by exp(scale - shift)
+  int q_scaled;             // 1: q already carries the factor c1 (fused l2norm writes c1 * q^); 0: the kernel applies it
 };
 
 struct BwdParams {
@@ -38,6 +39,7 @@ struct BwdParams {
   int causal, bias_batch;
   float c1, c2, bias_c;
   float scale;
+  int q_scaled;             // see FwdParams
 };
 
 struct NormParams {         // grouped l2norm forward:  x -> xn, inv_norm
@@ -46,6 +48,7 @@ struct NormParams {         // grouped l2norm forward:  x -> xn, inv_norm
   float* inv_norm;          // contiguous [B,H,L,G] or nullptr
   int B, H, L, D, G;
   float eps;
+  float out_scale;          // xn = out_scale * x / max(||x||, eps)   (c1 for q in the fused path, else 1)
 };
 
 struct NormBwdParams {      // dx = reduce_heads(slab) then (optionally) l2norm backward
@@ -57,6 +60,7 @@ struct NormBwdParams {      // dx = reduce_heads(slab) then (optionally) l2norm 
   View dx;                  // [B,HO,L,D] out (dtype)
   int B, HO, L, D, G;
   float eps;
+  float xn_scale;           // x^ = xn_scale * xn   (1/c1 when xn was written with out_scale = c1)
 };
 
 // dtype: 1 = f16, 2 = bf16 (fcsa_dtype); returns hipError_t of the launch

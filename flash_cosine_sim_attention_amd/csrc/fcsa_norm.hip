@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) {
   const float inv = 1.f / fmaxf(sqrtf(ss), p.eps);          // F.normalize: x / max(||x||, eps)
   if (m.active) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] *= inv;
+    for (int e = 0; e < 8; ++e) f[e] *= inv * p.out_scale;
     store8<T>(p.xn + (m.row * p.D + m.c * 8) * Traits<T>::ES, f);
     if (p.inv_norm != nullptr && (m.c % lpg) == 0) p.inv_norm[m.row * p.G + m.c / lpg] = inv;
   }
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) l2norm_generic_kernel(const NormParams p)
   float ss = 0.f;
   for (int e = 0; e < dg; ++e) { const float v = (float)x[e]; ss += v * v; }
   const float inv = 1.f / fmaxf(sqrtf(ss), p.eps);
-  for (int e = 0; e < dg; ++e) xn[e] = (E)((float)x[e] * inv);
+  for (int e = 0; e < dg; ++e) xn[e] = (E)((float)x[e] * inv * p.out_scale);
   if (p.inv_norm != nullptr) p.inv_norm[idx] = inv;
 }
 
@@ -157,7 +157,11 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) 
         for (int e = 0; e < 8; ++e) g[e] += t[e];
       }
     }
-    if (norm) load8<T>(p.xn + (m.row * p.D + m.c * 8) * Traits<T>::ES, xh);
+    if (norm) {
+      load8<T>(p.xn + (m.row * p.D + m.c * 8) * Traits<T>::ES, xh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xh[e] *= p.xn_scale;
+    }
   }
   if (norm) {
     float dot = 0.f;
@@ -205,12 +209,12 @@ __global__ void __launch_bounds__(256) l2norm_bwd_generic_kernel(const NormBwdPa
     return;
   }
   float dot = 0.f;
-  for (int e = 0; e < dg; ++e) dot += grad(e) * (float)xn[e];
+  for (int e = 0; e < dg; ++e) dot += grad(e) * (float)xn[e] * p.xn_scale;
   const float r = p.inv_norm[idx];
   const bool clamped = r >= 1.f / p.eps;
   for (int e = 0; e < dg; ++e) {
     const float ge = grad(e);
-    dx[e] = (E)(clamped ? ge * r : r * (ge - (float)xn[e] * dot));
+    dx[e] = (E)(clamped ? ge * r : r * (ge - (float)xn[e] * p.xn_scale * dot));
   }
 }
 
