@@ -63,10 +63,11 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
   }
 }
 
-// One 64-key tile for one wave.  Software-pipelined on purpose (ablation: the K row-fragment ds_read_b128,
-// when issued just in time in front of their dependent MFMA, were the most expensive item of the tile):
-//   all K fragments of BOTH 32-key blocks are requested first, both S chains are issued back to back, and the
-//   V^T fragments of a block are requested before its exp phase, so LDS latency hides under MFMA / VALU work.
+// One 64-key tile for one wave.  Software-pipelined INSIDE the wave (in-order issue: the matrix pipe and the VALU
+// only overlap if their instructions alternate in program order):
+//     K requests | S0 chain | V requests | S1 chain  x exp(block 0) | PV(block 0) x exp(block 1) | PV(block 1)
+// The ablation that motivated it: K row fragments requested just in time cost 27% of the kernel, and two
+// co-resident workgroups ran only 1.24x faster than one, i.e. other waves do not hide a serial chain.
 template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
@@ -89,35 +90,101 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(kt, 32 * jb, kk);
   __builtin_amdgcn_sched_barrier(0);     // keep the K requests up here (the scheduler otherwise sinks them next to each MFMA)
-  f32x16 s[2];
+
+  if constexpr (TR::ES == 2 && !BIAS) {
+    constexpr int MFMA = 0x8, VALU = 0x2 | 0x400, DSR = 0x100;
+    f32x16 s0, s1;
 #pragma unroll
-  for (int jb = 0; jb < 2; ++jb) {
+    for (int r = 0; r < 16; ++r) { s0[r] = -p.c2; s1[r] = -p.c2; }   // exponent shift as the accumulator's initial value
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[jb][r] = -p.c2;      // exponent shift as the accumulator's initial value: no per-element fma
+    for (int kk = 0; kk < G::KS; ++kk) s0 = TR::mfma32(kf[0][kk], qf[kk], s0);
+    u32x4 vf0[G::DB][2], vf1[G::DB][2];
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) s[jb] = TR::mfma32(kf[jb][kk], qf[kk], s[jb]);
-  }
+    for (int db = 0; db < G::DB; ++db) { vf0[db][0] = fa.tr_frag(vt, 0, db); vf0[db][1] = fa.tr_frag(vt, 16, db); }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- S1 chain interleaved with exp / pack of block 0
 #pragma unroll
-  for (int jb = 0; jb < 2; ++jb) {
-    SecondB<T> pb;
-    if constexpr (TR::ES == 2) {
-      u32x4 vf[G::DB][2];                        // V^T fragments of this block, requested before the exp phase
+    for (int kk = 0; kk < G::KS; ++kk) s1 = TR::mfma32(kf[1][kk], qf[kk], s1);
+    SecondB<T> pb0, pb1;
 #pragma unroll
-      for (int db = 0; db < G::DB; ++db) {
-        vf[db][0] = fa.tr_frag(vt, 32 * jb, db);
-        vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db);
+    for (int r = 0; r < 16; ++r) {
+      float e = fast_exp2(s0[r]);
+      if constexpr (MASKED) e = ((w[0] >> crow(r, 0)) & 1u) ? e : 0.f;
+      s0[r] = e;
+    }
+    pb0.prep(s0);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) { vf1[db][0] = fa.tr_frag(vt, 32, db); vf1[db][1] = fa.tr_frag(vt, 48, db); }
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(VALU, (MASKED ? 48 : 26) / G::KS + 1, 0);
+      __builtin_amdgcn_sched_group_barrier(DSR, (4 * G::DB + G::KS - 1) / G::KS, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- PV of block 0 (row sum + DB output blocks) interleaved with exp / pack of block 1
+    const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
+    lacc = TR::mfma32(ones, pb0.v[0], lacc);
+    lacc = TR::mfma32(ones, pb0.v[1], lacc);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      o[db] = TR::mfma32(vf0[db][0], pb0.v[0], o[db]);
+      o[db] = TR::mfma32(vf0[db][1], pb0.v[1], o[db]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = fast_exp2(s1[r]);
+      if constexpr (MASKED) e = ((w[1] >> crow(r, 0)) & 1u) ? e : 0.f;
+      s1[r] = e;
+    }
+    pb1.prep(s1);
+    constexpr int NPV = 2 + 2 * G::DB;
+#pragma unroll
+    for (int m = 0; m < NPV; ++m) {
+      __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(VALU, (MASKED ? 48 : 26) / NPV + 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- PV of block 1
+    lacc = TR::mfma32(ones, pb1.v[0], lacc);
+    lacc = TR::mfma32(ones, pb1.v[1], lacc);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      o[db] = TR::mfma32(vf1[db][0], pb1.v[0], o[db]);
+      o[db] = TR::mfma32(vf1[db][1], pb1.v[1], o[db]);
+    }
+  } else {
+    // generic order (f32, bias): both S chains first, then per block: softmax, PV
+    f32x16 s[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[jb][r] = -p.c2;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) s[jb] = TR::mfma32(kf[jb][kk], qf[kk], s[jb]);
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      SecondB<T> pb;
+      if constexpr (TR::ES == 2) {
+        u32x4 vf[G::DB][2];
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) {
+          vf[db][0] = fa.tr_frag(vt, 32 * jb, db);
+          vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) {
+          o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
+          o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
+        }
+      } else {
+        fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
       }
-      __builtin_amdgcn_sched_barrier(0);   // V^T requests stay ahead of the exp phase
-      fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
-#pragma unroll
-      for (int db = 0; db < G::DB; ++db) {
-        o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
-        o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
-      }
-    } else {
-      fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
-#pragma unroll
-      for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
     }
   }
 }
