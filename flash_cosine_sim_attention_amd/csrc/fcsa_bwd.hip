@@ -231,7 +231,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 
   if (i < p.N) {
     char* row = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)i * p.dq.sn;
-    store_row_tile<T, D>(row, dq, p.scale, fa.hi, p.dq_f32 != 0);     // cu:1580-1582: dS *= scale
+    if (p.rq != nullptr) {      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
+      const char* xrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+      store_row_tile_l2norm_bwd<T, D>(row, dq, p.scale, fa.hi, xrow, p.q_scaled ? 1.f / p.c1 : 1.f,
+                                      p.rq + (((int64_t)b * p.H + h) * p.N + i) * p.G, p.lgm, p.norm_eps);
+    } else {
+      store_row_tile<T, D>(row, dq, p.scale, fa.hi, p.dq_f32 != 0);     // cu:1580-1582: dS *= scale
+    }
   }
   }   // pass
 }
@@ -436,7 +442,14 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     char* dkrow = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)j * p.dk.sn;
     char* dvrow = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)j * p.dv.sn;
     // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
-    store_row_tile<T, D>(dkrow, dk, p.q_scaled ? p.scale / p.c1 : p.scale, fa.hi, p.dk_f32 != 0);
+    const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
+    if (p.rk != nullptr) {      // dk = l2norm_backward(dKh): p.k holds k^ (K/V with heads only)
+      const char* xrow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
+      store_row_tile_l2norm_bwd<T, D>(dkrow, dk, kmul, fa.hi, xrow, 1.f,
+                                      p.rk + (((int64_t)b * p.H + h) * p.M + j) * p.G, p.lgm, p.norm_eps);
+    } else {
+      store_row_tile<T, D>(dkrow, dk, kmul, fa.hi, p.dk_f32 != 0);
+    }
     store_row_tile<T, D>(dvrow, dv, 1.f, fa.hi, p.dv_f32 != 0);
   }
   }   // pass

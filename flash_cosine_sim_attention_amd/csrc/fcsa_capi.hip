@@ -109,16 +109,29 @@ float rowsum_eps(const fcsa_problem& p) {
 
 struct BwdLayout {
   size_t delta, dq_slab, dk_slab, dv_slab, total;
-  bool need_dq_slab, need_dk_slab, need_dv_slab;
+  bool need_dq_slab, need_dk_slab, need_dv_slab, fuse_norm;
 };
+
+int log2_blocks_per_group(const fcsa_problem& p) {     // log2(group size / 8), or -1 if not a power of two of 8-blocks
+  const int dg = p.dim_head / (p.groups > 0 ? p.groups : 1);
+  if (dg % 8 != 0) return -1;
+  int m = dg / 8, lg = 0;
+  while ((1 << lg) < m) ++lg;
+  return (1 << lg) == m ? lg : -1;
+}
+bool fusable_groups(const fcsa_problem& p) { return log2_blocks_per_group(p) >= 0; }
 
 BwdLayout bwd_layout(const fcsa_problem& p) {
   BwdLayout L;
   const bool single = p.kv_heads == 1 && p.heads > 1;
   const size_t qn = (size_t)p.batch * p.heads * p.q_len;
   const size_t kn = (size_t)p.batch * p.heads * p.k_len;      // slabs are per q-head
-  L.need_dq_slab = p.l2norm_qk != 0;
-  L.need_dk_slab = p.l2norm_qk != 0 || single;
+  // the l2norm backward is fused into the dQ / dKV epilogues when every group is 8 * 2^k features wide;
+  // otherwise (odd group sizes) and for the head reduction of single-headed K/V the kernels write f32
+  // slabs that the finalize kernel reduces / differentiates.
+  L.fuse_norm = p.l2norm_qk != 0 && fusable_groups(p);
+  L.need_dq_slab = p.l2norm_qk != 0 && !L.fuse_norm;
+  L.need_dk_slab = single || (p.l2norm_qk != 0 && !L.fuse_norm);
   L.need_dv_slab = single;
   size_t off = 0;
   L.delta = off;   off = align_up(off + qn * 4, 256);
@@ -339,6 +352,9 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.bias_c = kLog2e;
   bp.scale = p.scale;
   bp.q_scaled = p.l2norm_qk ? 1 : 0;
+  bp.G = p.groups; bp.lgm = L.fuse_norm ? log2_blocks_per_group(p) : 0; bp.norm_eps = 1e-12f;
+  bp.rq = L.fuse_norm ? a->norm.rq : nullptr;                       // fused: dq kernel writes the final dq
+  bp.rk = (L.fuse_norm && !single) ? a->norm.rk : nullptr;          // fused: dkv kernel writes the final dk
 
   // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
   if (int rc = timed("bwd_dq", "backward dq", s, [&] { return fcsa::launch_backward_dq(p.dtype, p.dim_head, bp, s); })) return rc;

@@ -317,14 +317,70 @@ FCSA_DEV void store_row_tile(char* row, const f32x16 (&acc)[TileGeom<D, Traits<T
     }
 }
 
+// sum of a per-lane value over the two half-waves (lane ^ 32)
+FCSA_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+
+// Fused l2norm backward + store of a C-layout gradient tile (epilogue of the dQ / dKV kernels).
+// The lane pair (row, hi = 0/1) holds the whole gradient row g = mul * acc w.r.t. the NORMALISED vector xh;
+// per group G of the row:  dx = r * (g - xh <g, xh>_G)   (r = 1/max(||x_G||, eps); dx = g * r where the norm was
+// clamped).  xh = xn_scale * xn is re-read from the saved normalised tensor (L2-resident), r from the saved
+// inverse norms.  Groups are (8 << lgm) features wide, lgm = log2(group size / 8): the 8-feature blocks
+// (db, rq) of the C layout never straddle a group.  Replaces an f32 slab round trip + a finalize launch.
+template <typename T, int D>
+FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileGeom<D, Traits<T>::ES>::DB], float mul, int hi,
+                                        const char* xn_row, float xn_scale, const float* inv_norm_row, int lgm, float eps) {
+  typedef Traits<T> TR;
+  constexpr int NB = D / 8;
+  float g[NB][4], xh[NB][4], bd[NB];
+#pragma unroll
+  for (int bq = 0; bq < NB; ++bq) {
+    const int db = bq >> 2, rq = bq & 3;
+    const int d0 = 32 * db + 8 * rq + 4 * hi;
+    if constexpr (TR::ES == 4) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xn_row + d0 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xh[bq][e] = x[e] * xn_scale;
+    } else {
+      const u32x2 x = *reinterpret_cast<const u32x2*>(xn_row + d0 * 2);
+      xh[bq][0] = TR::lo(x[0]) * xn_scale; xh[bq][1] = TR::hi(x[0]) * xn_scale;
+      xh[bq][2] = TR::lo(x[1]) * xn_scale; xh[bq][3] = TR::hi(x[1]) * xn_scale;
+    }
+    float pd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[bq][e] = acc[db][4 * rq + e] * mul; pd += g[bq][e] * xh[bq][e]; }
+    bd[bq] = xhalf_sum(pd);
+  }
+#pragma unroll
+  for (int bq = 0; bq < NB; ++bq) {
+    const int db = bq >> 2, rq = bq & 3;
+    const int d0 = 32 * db + 8 * rq + 4 * hi;
+    const int gid = bq >> lgm;
+    float dot = 0.f;
+#pragma unroll
+    for (int b2 = 0; b2 < NB; ++b2) dot += ((b2 >> lgm) == gid) ? bd[b2] : 0.f;
+    const float r = inv_norm_row[gid];
+    const bool clamped = r >= 1.f / eps;
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = clamped ? g[bq][e] * r : r * (g[bq][e] - xh[bq][e] * dot);
+    if constexpr (TR::ES == 4) {
+      f32x4 v = {o4[0], o4[1], o4[2], o4[3]};
+      *reinterpret_cast<f32x4*>(out_row + d0 * 4) = v;
+    } else {
+      u32x2 v;
+      v[0] = TR::pack2(o4[0], o4[1]);
+      v[1] = TR::pack2(o4[2], o4[3]);
+      *reinterpret_cast<u32x2*>(out_row + d0 * 2) = v;
+    }
+  }
+}
+
 #ifdef FCSA_EXPERIMENT_FAKE_EXP      // timing experiment only (wrong numerics): a full-rate op instead of v_exp_f32
 FCSA_DEV float fast_exp2(float x) { return x * 0.001f; }
 #else
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
 
-// sum of a per-lane value over the two half-waves (lane ^ 32)
-FCSA_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32, 64); }
 
 // bit mask (over accumulator-row positions 0..31) of positions <= thr
 FCSA_DEV uint32_t le_mask(int thr) { return thr < 0 ? 0u : (thr >= 31 ? 0xffffffffu : ((2u << thr) - 1u)); }

@@ -40,6 +40,11 @@ struct BwdParams {
   float c1, c2, bias_c;
   float scale;
   int q_scaled;             // see FwdParams
+  // fused l2norm backward in the epilogues (group size multiple of 8 with a power-of-two number of 8-blocks):
+  const float* rq;          // [B,H,N,G] inverse norms of q, or nullptr: dq kernel writes plain dQ^ (dtype or f32 slab)
+  const float* rk;          // [B,H,M,G] inverse norms of k, or nullptr (never set for single-headed K/V)
+  int G, lgm;               // groups; log2(group size / 8)
+  float norm_eps;           // 1e-12
 };
 
 struct NormParams {         // grouped l2norm forward:  x -> xn, inv_norm

@@ -108,14 +108,20 @@ def test_validation_errors_without_gpu(lib):
 
 
 def test_backward_workspace_formula(lib):
-    # delta [B,H,N] f32 always; f32 slabs: dq when l2norm, dk when l2norm or single-head kv, dv when single-head kv
+    # delta [B,H,N] f32 always.  f32 slabs only where the epilogues cannot finish the job:
+    #   dq, dk when l2norm groups are not 8 * 2^k features wide (finalize kernel does the l2norm backward),
+    #   dk, dv for single-headed K/V (finalize kernel reduces over heads).
     al = lambda x: (x + 255) // 256 * 256
     B, H, N, M, D = 2, 4, 100, 120, 64
     p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=D)
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4)
-    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=D, l2norm_qk=1)
-    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + al(B * H * N * D * 4) + al(B * H * M * D * 4)
+    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=D, l2norm_qk=1, groups=2)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4)                      # fused epilogues
+    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=96, l2norm_qk=1, groups=8)   # group size 12
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + al(B * H * N * 96 * 4) + al(B * H * M * 96 * 4)
     p = _problem(batch=B, heads=H, kv_heads=1, q_len=N, k_len=M, dim_head=D)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + 2 * al(B * H * M * D * 4)
+    p = _problem(batch=B, heads=H, kv_heads=1, q_len=N, k_len=M, dim_head=D, l2norm_qk=1)
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + 2 * al(B * H * M * D * 4)
 
 
