@@ -356,8 +356,13 @@ FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileG
     const int d0 = 32 * db + 8 * rq + 4 * hi;
     const int gid = bq >> lgm;
     float dot = 0.f;
+    if (((NB - 1) >> lgm) == 0) {      // one group (groups = 1): plain sum, wave-uniform branch
 #pragma unroll
-    for (int b2 = 0; b2 < NB; ++b2) dot += ((b2 >> lgm) == gid) ? bd[b2] : 0.f;
+      for (int b2 = 0; b2 < NB; ++b2) dot += bd[b2];
+    } else {
+#pragma unroll
+      for (int b2 = 0; b2 < NB; ++b2) dot += ((b2 >> lgm) == gid) ? bd[b2] : 0.f;
+    }
     const float r = inv_norm_row[gid];
     const bool clamped = r >= 1.f / eps;
     float o4[4];
