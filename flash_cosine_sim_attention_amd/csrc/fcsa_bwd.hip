@@ -53,13 +53,24 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     uint32_t w = 0xffffffffu;
     if constexpr (MASKED)
       w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+    // request every row fragment of this 32-key block first (just-in-time ds_read_b128 in front of their
+    // dependent MFMA were the most expensive item of the forward tile, see fwd_tile)
+    // (requests are batched PF k-steps at a time so the live fragments stay within the register budget)
+    constexpr int PF = G::KS <= 4 ? G::KS : 2;
     f32x16 s, dp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = 0.f; }     // lc = log2(inv_l) - c2 rides in as the initial value
+    for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = -delta; }  // lc = log2(inv_l) - c2 and -delta ride in as initial values
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(kt, 32 * jb, kk), qf[kk], s);
+    for (int k0 = 0; k0 < G::KS; k0 += PF) {
+      u32x4 kfr[PF], vfr[PF];
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(vt, 32 * jb, kk), dof[kk], dp);
+      for (int kk = 0; kk < PF; ++kk) { kfr[kk] = fa.row_frag(kt, 32 * jb, k0 + kk); vfr[kk] = fa.row_frag(vt, 32 * jb, k0 + kk); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < PF; ++kk) s = TR::mfma32(kfr[kk], qf[k0 + kk], s);
+#pragma unroll
+      for (int kk = 0; kk < PF; ++kk) dp = TR::mfma32(vfr[kk], dof[k0 + kk], dp);
+    }
 
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
@@ -76,7 +87,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       if constexpr (BIAS) x += bv[r];
       float e = fast_exp2(x);
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
-      const float ds = e * (dp[r] - delta);
+      const float ds = e * dp[r];        // dp already holds dP - delta
       if constexpr (BIAS) {
         const int j = jbase + crow(r, 0);
         if (dbias_row != nullptr && j < p.M && ds != 0.f) atomicAdd(dbias_row + j, ds);   // cu:1574-1576
@@ -259,14 +270,16 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     // Branch-free and before the MFMA chains on purpose (see fwd_tile).
     uint32_t w = 0xffffffffu;
     if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
-    f32x16 s, dp, dl;
+    f32x16 s, dp;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {      // per-query log-normaliser as the accumulator's initial value; delta kept for dS
+    for (int rq = 0; rq < 4; ++rq) {      // per-query log-normaliser and -delta (negated at staging) as the accumulators' initial values
       const f32x4 lc4 = *reinterpret_cast<const f32x4*>(lcs + 32 * ib + 8 * rq + 4 * fa.hi);
-      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dls + 32 * ib + 8 * rq + 4 * fa.hi);
+      const f32x4 nd4 = *reinterpret_cast<const f32x4*>(dls + 32 * ib + 8 * rq + 4 * fa.hi);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s[4 * rq + e] = lc4[e]; dl[4 * rq + e] = dl4[e]; dp[4 * rq + e] = 0.f; }
+      for (int e = 0; e < 4; ++e) { s[4 * rq + e] = lc4[e]; dp[4 * rq + e] = nd4[e]; }
     }
+    // (row fragments are requested next to their MFMA here: this kernel sits at its register budget, and
+    //  batching the requests as in dq_tile spills)
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
 #pragma unroll
@@ -285,7 +298,7 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
       float pe = fast_exp2(x);
       if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
       pr[r] = pe;
-      s[r] = pe * (dp[r] - dl[r]);
+      s[r] = pe * dp[r];             // dp already holds dP - delta
     }
     SecondB<T> pp, pd;
     pp.prep(pr);
@@ -391,7 +404,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     if (tid < BMQ) {
       // rows beyond N: lc = -inf makes P exactly 0 there
       reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -INFINITY;
-      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? dl_r : 0.f;
+      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? -dl_r : 0.f;      // -delta
     }
   };
 
