@@ -493,7 +493,7 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   constexpr int NW = 4, BNK = 32 * NW;
-  constexpr int BMQ = (Traits<T>::ES == 4 && D >= 96) ? 32 : 64;   // f32 at D >= 96: halve the staged tile (VGPR budget)
+  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : 64;   // wide rows (16-bit D >= 96, f32 D >= 64): halve the staged tile (VGPR budget)
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);

@@ -331,23 +331,28 @@ FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileG
                                         const char* xn_row, float xn_scale, const float* inv_norm_row, int lgm, float eps) {
   typedef Traits<T> TR;
   constexpr int NB = D / 8;
-  float g[NB][4], xh[NB][4], bd[NB];
-#pragma unroll
-  for (int bq = 0; bq < NB; ++bq) {
-    const int db = bq >> 2, rq = bq & 3;
-    const int d0 = 32 * db + 8 * rq + 4 * hi;
+  // xh is read twice (dot pass, output pass) instead of being kept: the accumulators of the other gradient are
+  // still live at this point and a second L2 read is cheaper than spilling
+  auto load_xh = [&](int bq, float (&xh)[4]) {
+    const int d0 = 32 * (bq >> 2) + 8 * (bq & 3) + 4 * hi;
     if constexpr (TR::ES == 4) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(xn_row + d0 * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xh[bq][e] = x[e] * xn_scale;
+      for (int e = 0; e < 4; ++e) xh[e] = x[e] * xn_scale;
     } else {
       const u32x2 x = *reinterpret_cast<const u32x2*>(xn_row + d0 * 2);
-      xh[bq][0] = TR::lo(x[0]) * xn_scale; xh[bq][1] = TR::hi(x[0]) * xn_scale;
-      xh[bq][2] = TR::lo(x[1]) * xn_scale; xh[bq][3] = TR::hi(x[1]) * xn_scale;
+      xh[0] = TR::lo(x[0]) * xn_scale; xh[1] = TR::hi(x[0]) * xn_scale;
+      xh[2] = TR::lo(x[1]) * xn_scale; xh[3] = TR::hi(x[1]) * xn_scale;
     }
+  };
+  float bd[NB];
+#pragma unroll
+  for (int bq = 0; bq < NB; ++bq) {
+    float xh[4];
+    load_xh(bq, xh);
     float pd = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g[bq][e] = acc[db][4 * rq + e] * mul; pd += g[bq][e] * xh[bq][e]; }
+    for (int e = 0; e < 4; ++e) pd += acc[bq >> 2][4 * (bq & 3) + e] * mul * xh[e];
     bd[bq] = xhalf_sum(pd);
   }
 #pragma unroll
@@ -365,9 +370,13 @@ FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileG
     }
     const float r = inv_norm_row[gid];
     const bool clamped = r >= 1.f / eps;
-    float o4[4];
+    float xh[4], o4[4];
+    load_xh(bq, xh);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o4[e] = clamped ? g[bq][e] * r : r * (g[bq][e] - xh[bq][e] * dot);
+    for (int e = 0; e < 4; ++e) {
+      const float g = acc[db][4 * rq + e] * mul;
+      o4[e] = clamped ? g * r : r * (g - xh[e] * dot);
+    }
     if constexpr (TR::ES == 4) {
       f32x4 v = {o4[0], o4[1], o4[2], o4[3]};
       *reinterpret_cast<f32x4*>(out_row + d0 * 4) = v;
