@@ -146,6 +146,15 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_gflop_per_launch": round(alg[dom["name"]] / 1e9, 2),
                         "timing": "hipEvent pairs recorded by libfcsa_hip on the launch stream over %d steps" % args.steps}
+            # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the value is
+            # the committed measurement of this same command (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes,
+            # FETCH_SIZE x2 gfx950 correction), if one has been recorded for this round.
+            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tfile):
+                tk = json.load(open(tfile)).get("kernels", {}).get(dom["name"] + "_kernel")
+                if tk:
+                    roofline["traffic"] = round(tk["total_bytes"])
+                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
 
     # ---- max |delta| vs a PyTorch f32 evaluation of the same math on (b,h) slices ----------------------
     max_delta = None

@@ -262,17 +262,16 @@ int fcsa_forward(const fcsa_forward_args* a) {
     const fcsa_norm_state& n = a->norm;
     if (n.qn == nullptr || n.kn == nullptr)
       return fail(FCSA_ERR_INVALID_ARG, "l2norm_qk needs norm.qn and norm.kn buffers");
-    fcsa::NormParams np;
-    np.eps = 1e-12f;
-    np.D = p.dim_head; np.G = p.groups;
-    np.x = fp.q; np.xn = static_cast<char*>(n.qn); np.inv_norm = n.rq;
-    np.B = p.batch; np.H = p.heads; np.L = p.q_len;
-    np.out_scale = p.scale * kLog2e;       // qn = c1 * q^ (one rounding): the kernels then need no per-logit multiply
-    if (int rc = timed("l2norm", "l2norm(q)", s, [&] { return fcsa::launch_l2norm(p.dtype, np, s); })) return rc;
-    np.x = view(a->k, es); np.xn = static_cast<char*>(n.kn); np.inv_norm = n.rk;
-    np.B = p.batch; np.H = p.kv_heads; np.L = p.k_len;
-    np.out_scale = 1.f;
-    if (int rc = timed("l2norm", "l2norm(k)", s, [&] { return fcsa::launch_l2norm(p.dtype, np, s); })) return rc;
+    fcsa::NormParams nq, nk;
+    nq.eps = nk.eps = 1e-12f;
+    nq.D = nk.D = p.dim_head; nq.G = nk.G = p.groups;
+    nq.x = fp.q; nq.xn = static_cast<char*>(n.qn); nq.inv_norm = n.rq;
+    nq.B = p.batch; nq.H = p.heads; nq.L = p.q_len;
+    nq.out_scale = p.scale * kLog2e;       // qn = c1 * q^ (one rounding): the kernels then need no per-logit multiply
+    nk.x = view(a->k, es); nk.xn = static_cast<char*>(n.kn); nk.inv_norm = n.rk;
+    nk.B = p.batch; nk.H = p.kv_heads; nk.L = p.k_len;
+    nk.out_scale = 1.f;
+    if (int rc = timed("l2norm", "l2norm(q,k)", s, [&] { return fcsa::launch_l2norm_pair(p.dtype, nq, nk, s); })) return rc;
     fp.q = contiguous_view(n.qn, p.heads, p.q_len, p.dim_head, es);
     fp.k = contiguous_view(n.kn, p.kv_heads, p.k_len, p.dim_head, es, single);
   }

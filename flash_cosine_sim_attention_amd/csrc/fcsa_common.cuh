@@ -389,11 +389,7 @@ FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileG
   }
 }
 
-#ifdef FCSA_EXPERIMENT_FAKE_EXP      // timing experiment only (wrong numerics): a full-rate op instead of v_exp_f32
-FCSA_DEV float fast_exp2(float x) { return x * 0.001f; }
-#else
-FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-#endif
+FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (2^x, quarter rate)
 
 
 // bit mask (over accumulator-row positions 0..31) of positions <= thr

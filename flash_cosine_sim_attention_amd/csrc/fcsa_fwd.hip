@@ -336,8 +336,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
-  if (const char* pad = getenv("FCSA_EXPERIMENT_LDS_KB")) lds = (size_t)atoi(pad) * 1024;   // occupancy experiments only
+  const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
   auto kern = fwd_kernel<T, D, NW, BIAS>;
   static bool attr_set = false;                  // per instantiation; the attribute is sticky
   if (!attr_set) {

@@ -73,6 +73,7 @@ hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s);
 hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t s);
 hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s);
+hipError_t launch_l2norm_pair(int dtype, const NormParams& a, const NormParams& b, hipStream_t s);   // q and k in one grid
 hipError_t launch_l2norm_bwd(int dtype, const NormBwdParams& p, hipStream_t s);
 
 }  // namespace fcsa

@@ -52,17 +52,33 @@ FCSA_DEV float group_sum(float v, int lpg, int pos_in_group, int lane) {
   return s;
 }
 
+// row index -> (batch, head, position).  64-bit integer division costs a few hundred VALU instructions on
+// gfx950, which dominated these short kernels; row counts below 2^31 (every realistic call) take the 32-bit path.
+FCSA_DEV void split_row(int64_t row, int64_t nrows, int L, int H, int& b, int& h, int& l) {
+  if (nrows <= 0x7fffffff) {
+    const uint32_t r = (uint32_t)row, bh = r / (uint32_t)L;
+    l = (int)(r - bh * (uint32_t)L);
+    b = (int)(bh / (uint32_t)H);
+    h = (int)(bh - (uint32_t)b * (uint32_t)H);
+  } else {
+    const int64_t bh = row / L;
+    l = (int)(row - bh * L);
+    b = (int)(bh / H);
+    h = (int)(bh - (int64_t)b * H);
+  }
+}
+
 struct RowMap {
   int tpr, rpw, lane, c;
   int64_t row;
   bool active;
-  FCSA_DEV void init(int D, int64_t nrows) {
+  FCSA_DEV void init(int D, int64_t nrows, int block = blockIdx.x) {
     tpr = D >> 3;
     rpw = 64 / tpr;
     lane = threadIdx.x & 63;
     const int r = lane / tpr;
     c = lane - r * tpr;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     row = wave * rpw + r;
     active = r < rpw && row < nrows;
   }
@@ -71,34 +87,50 @@ struct RowMap {
 // ---------------------------------------------------------------------------------------------
 // forward, group size multiple of 8
 // ---------------------------------------------------------------------------------------------
+constexpr int kNormUnroll = 4;      // row chunks per block: all loads of a thread are issued before the first use
+
 template <typename T>
-__global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) {
-  RowMap m;
+FCSA_DEV void l2norm_rows(const NormParams& p, int block) {
   const int64_t nrows = (int64_t)p.B * p.H * p.L;
-  m.init(p.D, nrows);
   const int dg = p.D / p.G, lpg = dg >> 3;
-  float f[8];
+  RowMap m[kNormUnroll];
+  float f[kNormUnroll][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) f[e] = 0.f;
-  int64_t bh = 0;
-  int l = 0;
-  if (m.active) {
-    bh = m.row / p.L;
-    l = (int)(m.row - bh * p.L);
-    const int b = (int)(bh / p.H), h = (int)(bh - (int64_t)b * p.H);
-    load8<T>(p.x.p + (int64_t)b * p.x.sb + (int64_t)h * p.x.sh + (int64_t)l * p.x.sn + m.c * 8 * Traits<T>::ES, f);
+  for (int u = 0; u < kNormUnroll; ++u) {
+    m[u].init(p.D, nrows, block * kNormUnroll + u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
+    if (m[u].active) {
+      int b, h, l;
+      split_row(m[u].row, nrows, p.L, p.H, b, h, l);
+      load8<T>(p.x.p + (int64_t)b * p.x.sb + (int64_t)h * p.x.sh + (int64_t)l * p.x.sn + m[u].c * 8 * Traits<T>::ES, f[u]);
+    }
   }
-  float ss = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-  ss = group_sum(ss, lpg, m.c % lpg, m.lane);
-  const float inv = 1.f / fmaxf(sqrtf(ss), p.eps);          // F.normalize: x / max(||x||, eps)
-  if (m.active) {
+  for (int u = 0; u < kNormUnroll; ++u) {
+    float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] *= inv * p.out_scale;
-    store8<T>(p.xn + (m.row * p.D + m.c * 8) * Traits<T>::ES, f);
-    if (p.inv_norm != nullptr && (m.c % lpg) == 0) p.inv_norm[m.row * p.G + m.c / lpg] = inv;
+    for (int e = 0; e < 8; ++e) ss += f[u][e] * f[u][e];
+    ss = group_sum(ss, lpg, m[u].c % lpg, m[u].lane);
+    const float inv = 1.f / fmaxf(sqrtf(ss), p.eps);          // F.normalize: x / max(||x||, eps)
+    if (m[u].active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[u][e] *= inv * p.out_scale;
+      store8<T>(p.xn + (m[u].row * p.D + m[u].c * 8) * Traits<T>::ES, f[u]);
+      if (p.inv_norm != nullptr && (m[u].c % lpg) == 0) p.inv_norm[m[u].row * p.G + m[u].c / lpg] = inv;
+    }
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) { l2norm_rows<T>(p, blockIdx.x); }
+
+// q and k of one attention call in ONE grid (both are short HBM-bound passes; a second launch costs
+// about as much as the pass itself): blocks [0, blocks_a) take `a`, the rest take `b`.
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_pair_kernel(const NormParams a, const NormParams b, const int blocks_a) {
+  if ((int)blockIdx.x < blocks_a) l2norm_rows<T>(a, blockIdx.x);
+  else l2norm_rows<T>(b, blockIdx.x - blocks_a);
 }
 
 // forward, any group size: one thread per (row, group)
@@ -138,10 +170,7 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) 
   for (int e = 0; e < 8; ++e) { g[e] = 0.f; xh[e] = 0.f; }
   int b = 0, h = 0, l = 0;
   if (m.active) {
-    const int64_t bh = m.row / p.L;
-    l = (int)(m.row - bh * p.L);
-    b = (int)(bh / p.HO);
-    h = (int)(bh - (int64_t)b * p.HO);
+    split_row(m.row, nrows, p.L, p.HO, b, h, l);
     const int nsum = (p.HS == p.HO) ? 1 : p.HS;
     for (int hs = 0; hs < nsum; ++hs) {
       const int64_t srow = ((int64_t)b * p.HS + (p.HS == p.HO ? h : hs)) * p.L + l;
@@ -225,7 +254,7 @@ static hipError_t launch_l2norm_t(const NormParams& p, hipStream_t s) {
   if (nrows == 0) return hipSuccess;
   const int dg = p.D / p.G;
   if (dg % 8 == 0) {
-    const int rows_per_block = 4 * (64 / (p.D / 8));
+    const int rows_per_block = kNormUnroll * 4 * (64 / (p.D / 8));
     hipLaunchKernelGGL(l2norm_kernel<T>, dim3((unsigned)((nrows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, p);
   } else {
     const int64_t total = nrows * p.G;
@@ -247,6 +276,28 @@ static hipError_t launch_l2norm_bwd_t(const NormBwdParams& p, hipStream_t s) {
     hipLaunchKernelGGL(l2norm_bwd_generic_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
   }
   return hipGetLastError();
+}
+
+// both tensors with the 16-byte row kernel in one launch; requires group size % 8 == 0 and equal D, G
+template <typename T>
+static hipError_t launch_l2norm_pair_t(const NormParams& a, const NormParams& b, hipStream_t s) {
+  const int rows_per_block = kNormUnroll * 4 * (64 / (a.D / 8));
+  const int64_t ra = (int64_t)a.B * a.H * a.L, rb = (int64_t)b.B * b.H * b.L;
+  const int64_t ba = (ra + rows_per_block - 1) / rows_per_block, bb = (rb + rows_per_block - 1) / rows_per_block;
+  if (ba + bb == 0) return hipSuccess;
+  hipLaunchKernelGGL(l2norm_pair_kernel<T>, dim3((unsigned)(ba + bb)), dim3(256), 0, s, a, b, (int)ba);
+  return hipGetLastError();
+}
+
+hipError_t launch_l2norm_pair(int dtype, const NormParams& a, const NormParams& b, hipStream_t s) {
+  if ((a.D / a.G) % 8 != 0 || a.D != b.D || a.G != b.G) {          // generic group sizes: two launches
+    const hipError_t e = launch_l2norm(dtype, a, s);
+    return e != hipSuccess ? e : launch_l2norm(dtype, b, s);
+  }
+  if (dtype == 2) return launch_l2norm_pair_t<BF16>(a, b, s);
+  if (dtype == 1) return launch_l2norm_pair_t<F16>(a, b, s);
+  if (dtype == 0) return launch_l2norm_pair_t<F32>(a, b, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s) {

@@ -25,8 +25,7 @@ def forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal):
     o, saved = _core.attention_forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal,
                                        l2norm_qk=False, groups=1, need_backward=should_backwards)
     inv_l = saved.inv_l if saved is not None else torch.empty((q.shape[0], 0), device=q.device, dtype=torch.float32)
-    if saved is not None and q.dim() == 3:
-        inv_l = inv_l                      # [BH, 1, N]: the reference keeps the unsqueezed head dim too (cu:1698)
+    # merged batch-heads (q.dim() == 3): inv_l stays [BH, 1, N]; the reference keeps the unsqueezed head dim too (cu:1698)
     return o, inv_l, should_backwards
 
 

@@ -32,7 +32,9 @@ def timeit(fn, iters=20, warm=10):
     return s.elapsed_time(e) / iters
 
 out = {}
-for name, c in CFG.items():
+sel = sys.argv[1:] or list(CFG)
+for name in sel:
+    c = CFG[name]
     g = torch.Generator(device="cuda").manual_seed(0)
     q = torch.randn(c["q"], device="cuda", dtype=c["dtype"], generator=g).requires_grad_(c["bwd"])
     k = torch.randn(c["kv"], device="cuda", dtype=c["dtype"], generator=g).requires_grad_(c["bwd"])
@@ -54,6 +56,7 @@ for name, c in CFG.items():
         r.update(fwdbwd_ms=round(t_fb, 4), fwdbwd_tflops=round(14 * unit / t_fb / 1e9, 1))
     # torch SDPA (softmax attention) on the same shapes, same protocol
     try:
+        if os.environ.get('NO_SDPA'): raise RuntimeError('sdpa skipped')
         ke, ve = (k, v) if k.dim() == 4 else (k[:, None].expand(B, H, M, D), v[:, None].expand(B, H, M, D))
         am = None if mask is None else mask[:, None, None, :].expand(B, 1, N, M)
         def sfwd():

@@ -11,6 +11,6 @@ run p2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INS
 run p3 FETCH_SIZE GRBM_GUI_ACTIVE
 run p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run p5 SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAVE32_INSTS SQ_INSTS_VALU_TRANS
-python "$R/tools/pmc_summary.py" "$O/p1" "$O/p2" "$O/p3" "$O/p4" "$O/p5" > "$R/gpurun_out/pmc_summary.txt" 2>&1
+PMC_TRAFFIC_JSON="$R/gpurun_out/pmc_traffic.json" python "$R/tools/pmc_summary.py" "$O/p1" "$O/p2" "$O/p3" "$O/p4" "$O/p5" > "$R/gpurun_out/pmc_summary.txt" 2>&1
 cat "$R/gpurun_out/pmc_summary.txt"
 find "$O" -name "*.db" -delete; find "$O" -name "*.csv" -size +8M -delete

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-kernel time breakdown (library HIP events) for a few shapes.  Measurement tool."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flash_cosine_sim_attention_amd as F
+from flash_cosine_sim_attention_amd import _lib
+
+SHAPES = {
+    "d64":   dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.bfloat16, causal=True, groups=1),
+    "d128":  dict(q=(4, 8, 4096, 128), kv=(4, 8, 4096, 128), dtype=torch.bfloat16, causal=True, groups=1),
+    "d128nc": dict(q=(4, 8, 2048, 128), kv=(4, 8, 2048, 128), dtype=torch.bfloat16, causal=False, groups=1),
+    "C5":    dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, groups=8),
+    "d32":   dict(q=(4, 8, 4096, 32), kv=(4, 8, 4096, 32), dtype=torch.bfloat16, causal=True, groups=1),
+    "d96":   dict(q=(4, 8, 4096, 96), kv=(4, 8, 4096, 96), dtype=torch.bfloat16, causal=True, groups=1),
+    "d64f32": dict(q=(2, 8, 2048, 64), kv=(2, 8, 2048, 64), dtype=torch.float32, causal=True, groups=1),
+}
+sel = sys.argv[1:] or list(SHAPES)
+for name in sel:
+    c = SHAPES[name]
+    q = torch.randn(c["q"], device="cuda", dtype=c["dtype"]).requires_grad_()
+    k = torch.randn(c["kv"], device="cuda", dtype=c["dtype"]).requires_grad_()
+    v = torch.randn(c["kv"], device="cuda", dtype=c["dtype"]).requires_grad_()
+    do = torch.randn(c["q"], device="cuda", dtype=c["dtype"])
+    def step():
+        q.grad = k.grad = v.grad = None
+        F.flash_cosine_sim_attention(q, k, v, causal=c["causal"], groups=c["groups"]).backward(do)
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(10): step()
+    torch.cuda.synchronize()
+    st = _lib.profile_collect()
+    _lib.profile_enable(False)
+    B, H, N, D = c["q"]; M = c["kv"][-2]
+    unit = B * H * N * M * D * (0.5 if c["causal"] else 1.0)
+    print(name, c["q"], "unit GFLOP", round(unit / 1e9, 2))
+    for s in st:
+        us = s["total_ms"] / s["calls"] * 1e3
+        mult = {"fwd": 4, "bwd_dq": 2, "bwd_dkv": 8}.get(s["name"], 0)
+        print(f"   {s['name']:<20} calls/step {s['calls']/10:.0f}  avg {us:8.1f} us" + (f"   {mult*unit/us/1e6:7.1f} TF" if mult else ""))
