@@ -67,6 +67,10 @@ template <> struct Traits<BF16> {
   static FCSA_DEV float lo(uint32_t u) { return as_f32(u << 16); }
   static FCSA_DEV float hi(uint32_t u) { return as_f32(u & 0xffff0000u); }
   static constexpr uint32_t kOne2 = 0x3f803f80u;     // two packed 1.0
+  // acc + lo(u) + hi(u): one v_dot2c_f32_bf16 against packed ones (exact f32 sum of the two ROUNDED values)
+  static FCSA_DEV float add_pair(uint32_t u, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, u), __builtin_bit_cast(bf16x2, kOne2), acc, false);
+  }
 };
 
 template <> struct Traits<F16> {
@@ -82,6 +86,9 @@ template <> struct Traits<F16> {
   static FCSA_DEV float lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
   static FCSA_DEV float hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
   static constexpr uint32_t kOne2 = 0x3c003c00u;     // two packed 1.0
+  static FCSA_DEV float add_pair(uint32_t u, float acc) {      // v_dot2c_f32_f16 against packed ones
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, u), __builtin_bit_cast(f16x2, kOne2), acc, false);
+  }
 };
 
 template <> struct Traits<F32> {
@@ -286,11 +293,19 @@ template <typename T, int D, int ROWS, int NT> struct Stager {
   }
   FCSA_DEV void store(char* tile, int tid) const {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / G::CPR, ch = c % G::CPR;
-      if (NCH % NT == 0 || c < NCH) *reinterpret_cast<u32x4*>(tile + G::off(row, ch)) = r[i];
-    }
+    for (int i = 0; i < PER; ++i) store_one(tile, tid, i);
+  }
+  // one chunk at a time, for kernels that place each memory instruction in a chosen issue slot
+  FCSA_DEV static __amdgpu_buffer_rsrc_t descriptor(const char* g, int64_t pitch, int rows_valid) {
+    int64_t bytes = rows_valid > 0 ? (int64_t)(rows_valid - 1) * pitch + ROW_BYTES : 0;
+    if (bytes > 0x7fffffff) bytes = 0x7fffffff;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, (int)bytes, 0x00020000);
+  }
+  FCSA_DEV void load_one(__amdgpu_buffer_rsrc_t rsrc, int i) { r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], 0, 0); }
+  FCSA_DEV void store_one(char* tile, int tid, int i) const {
+    const int c = tid + i * NT;
+    const int row = c / G::CPR, ch = c % G::CPR;
+    if (NCH % NT == 0 || c < NCH) *reinterpret_cast<u32x4*>(tile + G::off(row, ch)) = r[i];
   }
 };
 
@@ -388,6 +403,42 @@ FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileG
     }
   }
 }
+
+// ---- in-kernel phase timing (trace builds only: make EXTRA=-DFCSA_TRACE OUT=../libfcsa_hip_trace.so) ----
+// s_memtime stamps are ISSUED at phase boundaries and only READ after an explicit lgkmcnt(0) at the end of
+// the iteration, so they do not add waits inside the pipeline (SMEM returns out of order: a pending stamp only
+// makes the compiler's lgkmcnt(n) waits marginally more conservative).  Product builds compile all of it away.
+#ifdef FCSA_TRACE
+struct Trace {
+  static constexpr int N = 12;
+  unsigned long long t[N];
+  unsigned long long acc[N];
+  unsigned long long iters;
+  FCSA_DEV void reset() { for (int k = 0; k < N; ++k) { t[k] = 0; acc[k] = 0; } iters = 0; }
+  FCSA_DEV void stamp(int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0" : "=s"(t[k]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // call once per iteration after the closing barrier; `last` = index of the last stamp taken
+  FCSA_DEV void close(int last) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t[0]), "+s"(t[1]), "+s"(t[2]), "+s"(t[3]), "+s"(t[4]), "+s"(t[5]), "+s"(t[6]), "+s"(t[7]),
+                 "+s"(t[8]), "+s"(t[9]), "+s"(t[10]), "+s"(t[11]));
+    for (int k = 0; k < last; ++k) acc[k] += t[k + 1] - t[k];
+    iters += 1;
+  }
+  FCSA_DEV void dump(unsigned long long* out, unsigned long long total) const {
+    for (int k = 0; k < N; ++k) out[k] = acc[k];
+    out[N] = iters;
+    out[N + 1] = total;
+  }
+};
+FCSA_DEV unsigned long long trace_now() { unsigned long long v; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v)); return v; }
+#define FCSA_STAMP(ts, k) (ts).stamp(k)
+#else
+struct Trace { FCSA_DEV void reset() {} FCSA_DEV void close(int) {} };
+#define FCSA_STAMP(ts, k) ((void)0)
+#endif
 
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (2^x, quarter rate)
 

@@ -30,6 +30,9 @@
 #include "fcsa_kernels.h"
 
 namespace fcsa {
+#ifdef FCSA_TRACE
+__device__ unsigned long long g_trace_fwd[128];
+#endif
 
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
 template <typename T, bool MASKED, bool BIAS>
@@ -64,15 +67,18 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
 }
 
 // One 64-key tile for one wave.  Software-pipelined INSIDE the wave (in-order issue: the matrix pipe and the VALU
-// only overlap if their instructions alternate in program order):
-//     K requests | S0 chain | V requests | S1 chain  x exp(block 0) | PV(block 0) x exp(block 1) | PV(block 1)
-// The ablation that motivated it: K row fragments requested just in time cost 27% of the kernel, and two
-// co-resident workgroups ran only 1.24x faster than one, i.e. other waves do not hide a serial chain.
-template <typename T, int D, bool MASKED, bool BIAS>
-FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
+// only overlap if their instructions alternate in program order) and ACROSS tiles:
+//     S0 chain | V requests | S1 chain  x exp(block 0) | mid() | PV(block 0) x exp(block 1) | PV(block 1)
+// `kf` holds this tile's K row fragments, requested by the caller one phase earlier.  mid() is the workgroup
+// barrier plus the K requests of the NEXT tile; it runs when every LDS read of this tile has been issued, so the
+// next tile's fragments land during the PV products instead of being waited for at the top of the next tile
+// (phase timing of the previous structure: 690 of 2490 cycles per tile were spent there, right after the barrier,
+// with all four waves bursting their K reads at once).
+template <typename T, int D, bool MASKED, bool BIAS, typename Mid>
+FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, f32x16& lacc, const FwdParams& p, uint64_t word, uint32_t ncm, int i, int j0, int diff,
-                       const char* bias_row) {
+                       const char* bias_row, Trace& ts, Mid&& mid) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   // validity bits of this lane's 16 keys per block.  Branch-free and BEFORE the MFMA chains on purpose: a runtime
@@ -84,12 +90,6 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     for (int jb = 0; jb < 2; ++jb)
       w[jb] = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
   }
-  u32x4 kf[2][G::KS];
-#pragma unroll
-  for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(kt, 32 * jb, kk);
-  __builtin_amdgcn_sched_barrier(0);     // keep the K requests up here (the scheduler otherwise sinks them next to each MFMA)
 
   if constexpr (TR::ES == 2 && !BIAS) {
     constexpr int MFMA = 0x8, VALU = 0x2 | 0x400, DSR = 0x100;
@@ -102,6 +102,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) { vf0[db][0] = fa.tr_frag(vt, 0, db); vf0[db][1] = fa.tr_frag(vt, 16, db); }
     __builtin_amdgcn_sched_barrier(0);
+    FCSA_STAMP(ts, 3);
     // --- S1 chain interleaved with exp / pack of block 0
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s1 = TR::mfma32(kf[1][kk], qf[kk], s1);
@@ -121,6 +122,9 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       __builtin_amdgcn_sched_group_barrier(VALU, (MASKED ? 48 : 26) / G::KS + 1, 0);
       __builtin_amdgcn_sched_group_barrier(DSR, (4 * G::DB + G::KS - 1) / G::KS, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    FCSA_STAMP(ts, 4);
+    mid();
     __builtin_amdgcn_sched_barrier(0);
     // --- PV of block 0 (row sum + DB output blocks) interleaved with exp / pack of block 1
     const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
@@ -145,6 +149,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       __builtin_amdgcn_sched_group_barrier(VALU, (MASKED ? 48 : 26) / NPV + 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    FCSA_STAMP(ts, 8);
     // --- PV of block 1
     lacc = TR::mfma32(ones, pb1.v[0], lacc);
     lacc = TR::mfma32(ones, pb1.v[1], lacc);
@@ -153,6 +158,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       o[db] = TR::mfma32(vf1[db][0], pb1.v[0], o[db]);
       o[db] = TR::mfma32(vf1[db][1], pb1.v[1], o[db]);
     }
+    FCSA_STAMP(ts, 9);
   } else {
     // generic order (f32, bias): both S chains first, then per block: softmax, PV
     f32x16 s[2];
@@ -186,6 +192,7 @@ FCSA_DEV void fwd_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
         for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
       }
     }
+    mid();
   }
 }
 
@@ -214,6 +221,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
   const int diff = p.M - p.N;                     // cu:1097 seq_len_diff
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
+  Trace ts;
+  ts.reset();
+#ifdef FCSA_TRACE
+  const unsigned long long trace_t0 = trace_now();
+#endif
   for (int pass = 0; pass < npass; ++pass) {
   const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
@@ -255,23 +267,45 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   if constexpr (BIAS)
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
 
+  // Pipeline (per 64-key tile t; two LDS buffers, one register staging set, ONE barrier per tile):
+  //   top of t : staging registers (tile t+1, loaded during t-1) -> LDS buffer (t+1)&1; global loads of tile t+2
+  //   tile t   : S chains / exp / V requests from buffer t&1, K fragments already in registers
+  //   mid()    : barrier (all LDS reads of tile t returned, tile t+1 visible), K fragment requests of tile t+1
+  //   PV products of tile t
+  // Buffer (t+1)&1 held tile t-1, whose last reads every wave completed before the barrier of t-1.
   Stager<T, D, BN, NT> sk, sv;
   sk.init(p.k.sn, tid);
   sv.init(p.v.sn, tid);
   uint8_t mb = 1;
+  u32x4 kf[2][G::KS];
+  auto request_k = [&](const char* kt) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(kt, 32 * jb, kk);
+  };
   if (nt > 0) {
     sk.load(kbase, p.k.sn, p.M);
     sv.load(vbase, p.v.sn, p.M);
     if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
+  }
+  // Every prologue load (Q fragments, first tile, mask byte) is complete here on the real path; say so on ALL
+  // paths.  Otherwise hipcc's waitcnt model keeps the Q loads pending along the no-tile path, the loop-header
+  // merge never clears that, and each iteration waits with vmcnt(0) at its first MFMA -- right after issuing
+  // the prefetch of tile t+2, which serialises the prefetch with the compute meant to hide it.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
+  if (nt > 0) {
     sk.store(smem, tid);
     sv.store(smem + TILE_B, tid);
+    if (nt > 1) {
+      sk.load(kbase + (int64_t)BN * p.k.sn, p.k.sn, p.M - BN);
+      sv.load(vbase + (int64_t)BN * p.v.sn, p.v.sn, p.M - BN);
+    }
   }
   __syncthreads();
-  // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
-  // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never
-  // clears that, and each iteration re-waits with vmcnt(0) at its first MFMA -- right after issuing the next
-  // tile's prefetch, which serialises the prefetch with the compute meant to hide it.
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
+  // K fragments of a tile are 8 * KS registers; 512-byte rows (f32, D = 128) cannot hold them across the PV products
+  constexpr bool PREFETCH_K = D * TR::ES < 512;
+  if (PREFETCH_K && nt > 0) request_k(smem);
 
   // tiles [0, t_split) need no masking for THIS wave, tiles [t_split, nt) do (wave-uniform split; both
   // loops execute one barrier per tile, so waves of one workgroup may sit in different loops)
@@ -286,38 +320,48 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     constexpr bool MASKED = decltype(masked_tag)::value;
     for (int t = t_begin; t < t_end; ++t) {
       const int j0 = t * BN;
-      const char* kcur = smem + (t & 1) * 2 * TILE_B;
-      const char* vcur = kcur + TILE_B;
+      const char* vcur = smem + (t & 1) * 2 * TILE_B + TILE_B;
       char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
-      const bool more = t + 1 < nt;
+      FCSA_STAMP(ts, 0);
       uint64_t word = 0;
       if constexpr (MASKED) {
         // consume the mask byte loaded one tile ago BEFORE issuing new loads (its wait then covers nothing else)
         word = __ballot((j0 + lane) < p.M && mb != 0);                  // valid keys of this tile
-        if (mrow && more) {
+        if (mrow && t + 1 < nt) {
           const int key = j0 + BN + lane;
           mb = key < p.M ? mrow[key] : (uint8_t)0;
         }
       }
-      if (more) {   // issue next tile's global loads now; they land while this tile is computed
-        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN));
-        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN));
-      }
-      if constexpr (MASKED) {
-        const bool skip = p.causal && (j0 > mw + 31 + diff);            // no valid pair for this wave
-        if (!skip) fwd_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row);
-      } else {
-        fwd_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, o, l, lacc, p, 0, ncm, i, j0, diff, bias_row);
-      }
-      if (more) {
+      if (t + 1 < nt) {
         sk.store(knxt, tid);
         sv.store(knxt + TILE_B, tid);
       }
-      __syncthreads();
+      FCSA_STAMP(ts, 1);
+      if (t + 2 < nt) {
+        sk.load(kbase + (int64_t)(j0 + 2 * BN) * p.k.sn, p.k.sn, p.M - (j0 + 2 * BN));
+        sv.load(vbase + (int64_t)(j0 + 2 * BN) * p.v.sn, p.v.sn, p.M - (j0 + 2 * BN));
+      }
+      FCSA_STAMP(ts, 2);
+      auto mid = [&]() {
+        FCSA_STAMP(ts, 5);
+        __syncthreads();
+        FCSA_STAMP(ts, 6);
+        if (PREFETCH_K && t + 1 < nt) request_k(knxt);
+        FCSA_STAMP(ts, 7);
+      };
+      bool skip = false;
+      if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
+      if (!PREFETCH_K && !skip) request_k(vcur - TILE_B);
+      if (skip) mid();
+      else fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row, ts, mid);
+      FCSA_STAMP(ts, 10);
+      if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only
     }
   };
   run(std::false_type{}, 0, t_split);
   run(std::true_type{}, t_split, nt);
+  // no trailing barrier: every wave completed its last LDS read before the final mid() barrier, so the next
+  // pass may overwrite buffer 0 in its prologue
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
   const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
@@ -328,6 +372,358 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     store_row_tile<T, D>(orow, o, inv, fa.hi, false);
   }
   }   // pass
+#ifdef FCSA_TRACE
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
+#endif
+}
+
+#ifdef FCSA_TRACE
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_fwd(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_fwd), sizeof(unsigned long long) * 128);
+}
+namespace fcsa {
+#endif
+
+// =============================================================================================
+// Wide forward kernel (16-bit types, no bias): every wave owns 64 query rows = two 32-row blocks that share each
+// K / V fragment, i.e. two MFMAs per LDS fragment read.  Motivation (phase timing + PMC of the 32-row kernel): a
+// 32-row wave moves 1 KiB through the LDS per 32x32x16 MFMA, so the CU's 128 B/clk LDS port is exactly as loaded
+// as its matrix pipes and the fragment requests of the four waves queue up behind each other (8 ds_read_b128
+// took ~400 cycles to ISSUE).  64 rows per wave halve that traffic; the two independent row blocks also give the
+// in-order wave two accumulator chains to alternate.  One workgroup (4 waves, 256 rows) per CU, so the
+// register budget is 512 per lane and nothing spills.  Row sums come from v_dot2c against packed ones on the
+// VALU (exact f32 sums of the rounded P~, like the ones-MFMA of the narrow kernel, without its 25% extra MFMAs).
+// Used when the grid still fills the chip (launch_forward); the narrow kernel covers everything else.
+// =============================================================================================
+// Rotating software pipeline of the wide kernel.  The wave issues in order, so the matrix pipe and the VALU overlap
+// only if their instructions alternate in PROGRAM order; hipcc's list scheduler follows sched_group_barrier hints
+// only loosely (it produced "4 MFMAs, then 22 v_exp"), so every MFMA gets its own fenced issue SLOT that also holds
+// a fixed share of the VALU work and at most a couple of memory instructions.  Per 64-key tile t, four phases:
+//
+//     P1  S0(t)    | softmax 2nd half of block 1 of tile t-1 | V requests block 0, stage store t+1, stage loads t+2
+//     P2  PV1(t-1) | softmax 1st half of block 0 of tile t
+//     P3  S1(t)    | softmax 2nd half of block 0 of tile t   | V requests block 1
+//     --  barrier (every LDS read of tile t has returned; tile t+1 is visible)
+//     P4  PV0(t)   | softmax 1st half of block 1 of tile t   | K requests of tile t+1
+//
+// i.e. the exp / pack / row-sum work of a 32-key block (32 values per lane) is spread two values per slot over the
+// 16 MFMAs that follow its S chain: 2 v_exp + v_cvt_pk + v_dot2c = 24 VALU cycles under a 32-cycle MFMA.  A block's
+// PV product runs one phase after its softmax completes; PV1 of the last tile is drained after the loop.
+template <typename T, int D> struct Fwd2State {
+  typedef TileGeom<D, 2> G;
+  f32x16 s0[2], s1[2];                  // logits [row block]
+  SecondB<T> pb0[2], pb1[2];            // packed P~ [row block]
+  u32x4 vf0[G::DB][2], vf1[G::DB][2];   // transposed V fragments [feature block][16-key step]
+  uint32_t w1[2];                       // validity bits of key block 1 of the tile whose softmax is still in flight
+};
+
+// two logits of one block: exp, (mask), pack, row sum.  c = 0..7 selects accumulator registers 2c, 2c+1
+template <typename T, bool MASKED>
+FCSA_DEV void soft2(const f32x16& s, uint32_t wm, SecondB<T>& pb, float& lr, int c) {
+  float e0 = fast_exp2(s[2 * c]), e1 = fast_exp2(s[2 * c + 1]);
+  if constexpr (MASKED) {
+    e0 = ((wm >> crow(2 * c, 0)) & 1u) ? e0 : 0.f;
+    e1 = ((wm >> crow(2 * c + 1, 0)) & 1u) ? e1 : 0.f;
+  }
+  const uint32_t u = Traits<T>::pack2(e0, e1);
+  pb.v[c >> 2][c & 3] = u;
+  lr = Traits<T>::add_pair(u, lr);
+}
+
+#define FCSA_FENCE() __builtin_amdgcn_sched_barrier(0)
+// items [m*N/S, (m+1)*N/S) of N items spread over S slots
+#define FCSA_SHARE(m, S, N, i) for (int i = (m) * (N) / (S); i < ((m) + 1) * (N) / (S); ++i)
+
+template <typename T, int D, bool MASKED, typename StageStore, typename StageLoad, typename Mid>
+FCSA_DEV void fwd2_tile(const char* vt, const char* knext, u32x4 (&kf)[2][TileGeom<D, 2>::KS], const FragAddr<T, D>& fa,
+                        const u32x4 (&qf)[2][TileGeom<D, 2>::KS], f32x16 (&o)[2][TileGeom<D, 2>::DB], float (&l)[2],
+                        Fwd2State<T, D>& st, const FwdParams& p, uint64_t word, uint32_t ncm, int i0, int j0, int diff,
+                        Trace& ts, StageStore&& stage_store, StageLoad&& stage_load, Mid&& mid) {
+  typedef TileGeom<D, 2> G;
+  typedef Traits<T> TR;
+  constexpr int NS = 2 * G::KS;          // MFMAs of an S phase
+  constexpr int NPV = 4 * G::DB;         // MFMAs of a PV phase
+  constexpr int NSTG = 2 * Stager<T, D, 64, 256>::PER;
+  uint32_t w[2][2] = {{0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}};     // [key block][row block]
+  if constexpr (MASKED) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        w[jb][r] = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i0 + 32 * r + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+  }
+  f32x16 cinit;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) cinit[e] = -p.c2;       // exponent shift as the accumulator's initial value
+  FCSA_FENCE();
+  FCSA_STAMP(ts, 0);
+  // ---- P1: S0(t) | second half of softmax(block 1, tile t-1) | V requests block 0, stage store, stage loads
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    const int kk = m >> 1, r = m & 1;
+    st.s0[r] = TR::mfma32(kf[0][kk], qf[r][kk], kk == 0 ? cinit : st.s0[r]);
+    FCSA_SHARE(m, NS, 8, c) soft2<T, MASKED>(st.s1[c >> 2], st.w1[c >> 2], st.pb1[c >> 2], l[c >> 2], 4 + (c & 3));
+    if (m < NS / 2) {
+      FCSA_SHARE(m, NS / 2, 2 * G::DB, f) st.vf0[f >> 1][f & 1] = fa.tr_frag(vt, 16 * (f & 1), f >> 1);
+    } else {
+      FCSA_SHARE(m - NS / 2, NS - NS / 2, NSTG, x) stage_store(x);     // after the V requests: LDS writes do not move across reads
+    }
+    FCSA_FENCE();
+  }
+  FCSA_STAMP(ts, 1);
+  // ---- P2: PV1(t-1) | first half of softmax(block 0, tile t) | stage loads of tile t+2 (after the stores: same registers)
+#pragma unroll
+  for (int m = 0; m < NPV; ++m) {
+    const int ks = m / (2 * G::DB), db = (m >> 1) % G::DB, r = m & 1;
+    o[r][db] = TR::mfma32(st.vf1[db][ks], st.pb1[r].v[ks], o[r][db]);
+    FCSA_SHARE(m, NPV, 8, c) soft2<T, MASKED>(st.s0[c >> 2], w[0][c >> 2], st.pb0[c >> 2], l[c >> 2], c & 3);
+    FCSA_SHARE(m, NPV, NSTG, x) stage_load(x);
+    FCSA_FENCE();
+  }
+  FCSA_STAMP(ts, 2);
+  // ---- P3: S1(t) | second half of softmax(block 0, tile t) | V requests block 1 (first half of the slots)
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    const int kk = m >> 1, r = m & 1;
+    st.s1[r] = TR::mfma32(kf[1][kk], qf[r][kk], kk == 0 ? cinit : st.s1[r]);
+    FCSA_SHARE(m, NS, 8, c) soft2<T, MASKED>(st.s0[c >> 2], w[0][c >> 2], st.pb0[c >> 2], l[c >> 2], 4 + (c & 3));
+    if (m < NS / 2) {
+      FCSA_SHARE(m, NS / 2, 2 * G::DB, f) st.vf1[f >> 1][f & 1] = fa.tr_frag(vt, 32 + 16 * (f & 1), f >> 1);
+    }
+    FCSA_FENCE();
+  }
+  st.w1[0] = w[1][0];
+  st.w1[1] = w[1][1];
+  FCSA_STAMP(ts, 3);
+  mid();                                   // barrier
+  FCSA_STAMP(ts, 4);
+  // ---- P4: PV0(t) | first half of softmax(block 1, tile t) | K requests of tile t+1
+#pragma unroll
+  for (int m = 0; m < NPV; ++m) {
+    const int ks = m / (2 * G::DB), db = (m >> 1) % G::DB, r = m & 1;
+    o[r][db] = TR::mfma32(st.vf0[db][ks], st.pb0[r].v[ks], o[r][db]);
+    FCSA_SHARE(m, NPV, 8, c) soft2<T, MASKED>(st.s1[c >> 2], w[1][c >> 2], st.pb1[c >> 2], l[c >> 2], c & 3);
+    FCSA_SHARE(m, NPV, 2 * G::KS, f) kf[f / G::KS][f % G::KS] = fa.row_frag(knext, 32 * (f / G::KS), f % G::KS);
+    FCSA_FENCE();
+  }
+  FCSA_STAMP(ts, 5);
+}
+template <typename T, int D, int NW>
+__global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
+  typedef TileGeom<D, 2> G;
+  typedef Traits<T> TR;
+  static_assert(TR::ES == 2, "16-bit types only");
+  constexpr int BN = 64, RW = 64, BM = RW * NW, NT = NW * 64;
+  constexpr int TILE_B = BN * G::ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FragAddr<T, D> fa;
+  fa.init(lane);
+
+  const int MT = (p.N + BM - 1) / BM;
+  const int PT = p.causal ? (MT + 1) / 2 : MT;                 // causal: pairs of row tiles (MT-1-pt, pt), constant work
+  int bh, pt;
+  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
+  const int b = bh / p.H, h = bh % p.H;
+  const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
+  const int diff = p.M - p.N;
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
+  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
+  Stager<T, D, BN, NT> sk, sv;
+  sk.init(p.k.sn, tid);
+  sv.init(p.v.sn, tid);
+  Trace ts;
+  ts.reset();
+#ifdef FCSA_TRACE
+  const unsigned long long trace_t0 = trace_now();
+#endif
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
+    const int m0 = mt * BM;
+    const int mw = m0 + wave * RW;                  // first query row of this wave
+    const int i0 = mw + (lane & 31);                // this lane's row in block 0; block 1 is i0 + 32
+    int last_key = p.M - 1;
+    if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
+    const int nt = last_key < 0 ? 0 : last_key / BN + 1;
+
+    u32x4 qf[2][G::KS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = i0 + 32 * r;
+      const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        qf[r][kk] = z;
+        if (i < p.N) qf[r][kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+        if (!p.q_scaled) qf[r][kk] = scale_frag<T>(qf[r][kk], p.c1);
+      }
+    }
+    f32x16 o[2][G::DB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[r][db][e] = 0.f;
+    float l[2] = {0.f, 0.f};          // per-lane partial row sums (this lane's 16 keys per block)
+
+    // pipeline state "nothing in flight": the logits of tile -1 exponentiate to 0 and its V fragments are 0
+    Fwd2State<T, D> st;
+    auto reset_pipe = [&]() {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st.s1[r][e] = -1e30f;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        st.pb1[r].v[0] = z;
+        st.pb1[r].v[1] = z;
+        st.w1[r] = 0xffffffffu;
+      }
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db) { const u32x4 z = {0u, 0u, 0u, 0u}; st.vf1[db][0] = z; st.vf1[db][1] = z; }
+    };
+    // second half of softmax(block 1) and PV1 of the last computed tile; leaves the pipeline empty
+    auto drain = [&]() {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) soft2<T, true>(st.s1[c >> 2], st.w1[c >> 2], st.pb1[c >> 2], l[c >> 2], 4 + (c & 3));
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) o[r][db] = TR::mfma32(st.vf1[db][ks], st.pb1[r].v[ks], o[r][db]);
+      reset_pipe();
+    };
+    reset_pipe();
+
+    // stage store of tile t+1 during tile t, global loads of tile t+2, one barrier per tile (see fwd_kernel)
+    uint8_t mb = 1;
+    u32x4 kf[2][G::KS];
+    if (nt > 0) {
+      sk.load(kbase, p.k.sn, p.M);
+      sv.load(vbase, p.v.sn, p.M);
+      if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) on ALL paths (see fwd_kernel)
+    if (nt > 0) {
+      sk.store(smem, tid);
+      sv.store(smem + TILE_B, tid);
+      sk.load(kbase + (int64_t)BN * p.k.sn, p.k.sn, nt > 1 ? p.M - BN : 0);
+      sv.load(vbase + (int64_t)BN * p.v.sn, p.v.sn, nt > 1 ? p.M - BN : 0);
+    }
+    __syncthreads();
+    if (nt > 0) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(smem, 32 * jb, kk);
+    }
+
+    int t_split = 0;                      // tiles [0, t_split): no masking for this wave
+    if (mrow == nullptr) {
+      t_split = p.M / BN;
+      if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);
+      t_split = min(t_split, nt);
+    }
+    auto run = [&](auto masked_tag, int t_begin, int t_end) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      for (int t = t_begin; t < t_end; ++t) {
+        const int j0 = t * BN;
+        const char* vcur = smem + (t & 1) * 2 * TILE_B + TILE_B;
+        char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+        uint64_t word = 0;
+        if constexpr (MASKED) {
+          word = __ballot((j0 + lane) < p.M && mb != 0);
+          if (mrow && t + 1 < nt) {
+            const int key = j0 + BN + lane;
+            mb = key < p.M ? mrow[key] : (uint8_t)0;
+          }
+        }
+        // All branch-free: a conditional would put the instruction into its own basic block, out of its issue slot.
+        // Past the last tile the stores fill the LDS buffer nobody reads any more, the loads carry a zero-record
+        // descriptor (no memory access, zeros returned) and the K requests read that unused buffer.
+        const int rows_next = t + 2 < nt ? p.M - (j0 + 2 * BN) : 0;
+        const __amdgpu_buffer_rsrc_t kd = Stager<T, D, BN, NT>::descriptor(kbase + (int64_t)(j0 + 2 * BN) * p.k.sn, p.k.sn, rows_next);
+        const __amdgpu_buffer_rsrc_t vd = Stager<T, D, BN, NT>::descriptor(vbase + (int64_t)(j0 + 2 * BN) * p.v.sn, p.v.sn, rows_next);
+        constexpr int PER = Stager<T, D, BN, NT>::PER;
+        auto stage_store = [&](int x) { if (x < PER) sk.store_one(knxt, tid, x); else sv.store_one(knxt + TILE_B, tid, x - PER); };
+        auto stage_load = [&](int x) { if (x < PER) sk.load_one(kd, x); else sv.load_one(vd, x - PER); };
+        auto mid = [&]() { __syncthreads(); };
+        if constexpr (MASKED) {
+          if (p.causal && j0 > mw + RW - 1 + diff) {      // every key of this and all later tiles is in this wave's future:
+            drain();                                      // finish what is in flight (idempotent), then only keep the
+#pragma unroll
+            for (int x = 0; x < 2 * PER; ++x) stage_store(x);   // workgroup's staging and barrier protocol going
+#pragma unroll
+            for (int x = 0; x < 2 * PER; ++x) stage_load(x);
+            __syncthreads();
+            continue;
+          }
+        }
+        fwd2_tile<T, D, MASKED>(vcur, knxt, kf, fa, qf, o, l, st, p, word, ncm, i0, j0, diff, ts, stage_store, stage_load, mid);
+        if constexpr (!MASKED) ts.close(5);
+      }
+    };
+    run(std::false_type{}, 0, t_split);
+    run(std::true_type{}, t_split, nt);
+    drain();
+
+
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = i0 + 32 * r;
+      const float inv = 1.f / fmaxf(xhalf_sum(l[r]), p.l_eps);
+      if (i < p.N) {
+        if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = inv;
+        char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
+        store_row_tile<T, D>(orow, o[r], inv, fa.hi, false);
+      }
+    }
+  }   // pass
+#ifdef FCSA_TRACE
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
+#endif
+}
+
+// Wide or narrow forward kernel (measured on MI355X, bf16, B4 H8: tools/fwd_ab.py).  The wide kernel needs enough
+// 256-row workgroups to cover the 256 CUs.  It wins where the MFMA share of a tile is large or the sequence is long
+// (D = 96: +25..34%; D = 32 / 64 non-causal: +3..22%; causal N = 8192: +5%); with causal masking and short sequences
+// its 256-row diagonal granularity costs more than the halved LDS traffic saves (N = 4096: -6%, N = 1024: -20%).
+template <int D>
+static bool use_wide_fwd(const FwdParams& p) {
+#ifdef FCSA_FORCE_NARROW_FWD      // A/B measurement builds only
+  return false;
+#endif
+  const int MT = (p.N + 255) / 256;
+  const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
+  if (wgs < 224) return false;
+  if (!p.causal) return D >= 32;
+  return D == 96 ? p.N >= 2048 : p.N >= 8192;
+}
+
+template <typename T, int D>
+static hipError_t launch_fwd2(const FwdParams& p, hipStream_t s) {
+  constexpr int NW = 4, BM = 64 * NW;
+  const int MT = (p.N + BM - 1) / BM;
+  const int PT = p.causal ? (MT + 1) / 2 : MT;
+  const size_t lds = 4 * 64 * TileGeom<D, 2>::ROWB;
+  auto kern = fwd2_kernel<T, D, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
+  return hipGetLastError();
 }
 
 template <typename T, int D, bool BIAS>
@@ -350,6 +746,9 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
 
 template <typename T, int D>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
+  if constexpr (Traits<T>::ES == 2 && D <= 96) {       // D = 128: the pipeline state does not fit 512 registers
+    if (p.bias == nullptr && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
+  }
   return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);
 }
 

@@ -1,0 +1,122 @@
+"""Parity of the WIDE forward kernel (64 query rows per wave, rotating MFMA / softmax pipeline; fcsa_fwd.hip fwd2_kernel).
+
+launch_forward picks it when the 256-row workgroups cover the chip (>= 224 of them) and
+  * not causal and dim_head >= 32, or
+  * causal and (dim_head == 96 and N >= 2048, or N >= 8192).
+The shapes below are chosen to land on it through the normal dispatch:
+  * many small heads (batch*heads = 224+), checked against the float64 oracle elementwise with the stated tolerances,
+  * the long causal shapes, checked on (batch, head) slices against a float32 PyTorch evaluation on the GPU
+    (the oracle is O(N^2) float64 numpy: too slow at N = 8192) and through the rows-sum-to-one identity.
+Gradients flow through the (unchanged) backward kernels and are compared as well, so a wrong inv_l or O would show.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# forward tolerances stated in DESIGN.md §5: |o - ref| <= atol * max|v| + rtol * |ref|
+TOL = {torch.float16: (5e-3, 2.0 ** -10), torch.bfloat16: (2e-2, 2.0 ** -7)}
+GRAD_REL = {torch.float16: 3e-3, torch.bfloat16: 1.2e-2}
+
+
+def _npf(t):
+    return t.detach().cpu().double().numpy()
+
+
+def _inputs(B, H, N, M, D, dtype, seed, kv_heads=None):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    Hk = H if kv_heads is None else kv_heads
+    q = torch.randn((B, H, N, D), device="cuda", dtype=dtype, generator=g)
+    k = torch.randn((B, Hk, M, D), device="cuda", dtype=dtype, generator=g)
+    v = torch.randn((B, Hk, M, D), device="cuda", dtype=dtype, generator=g)
+    return q, k, v
+
+
+WIDE_SMALL = [
+    # B, H, N,   M,   D,  dtype,           mask,  groups, scale
+    (7, 32, 300, 300, 64, torch.bfloat16, False, 1, 8),
+    (7, 32, 300, 333, 64, torch.float16, True, 1, 8),       # ragged N and M, key padding mask
+    (8, 28, 257, 190, 32, torch.bfloat16, False, 2, 10),    # N just past one 256-row tile, grouped l2norm
+    (4, 60, 256, 64, 96, torch.float16, False, 1, 8),       # exactly one key tile
+    (4, 60, 320, 129, 96, torch.bfloat16, True, 3, 6),      # tail key tile of 1 key
+    (14, 16, 512, 512, 64, torch.float16, False, 1, 16),    # larger scale
+    (5, 48, 270, 70, 32, torch.float16, True, 1, 8),
+]
+
+
+@pytest.mark.parametrize("B,H,N,M,D,dtype,use_mask,groups,scale", WIDE_SMALL)
+def test_wide_forward_matches_oracle(B, H, N, M, D, dtype, use_mask, groups, scale):
+    import flash_cosine_sim_attention_amd as F
+    from oracle import cosine_sim_oracle as O
+    assert B * H * ((N + 255) // 256) >= 224, "shape would not dispatch to the wide kernel"
+    q, k, v = _inputs(B, H, N, M, D, dtype, seed=B * 1000 + N)
+    mask = None
+    if use_mask:
+        g = torch.Generator(device="cuda").manual_seed(7)
+        mask = torch.rand((B, M), device="cuda", generator=g) > 0.3
+        mask[:, 0] = True
+        mask[1, :] = False                     # one batch element without any valid key: rows must come out 0
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups)
+    do = torch.randn(o.shape, device="cuda", dtype=dtype, generator=torch.Generator(device="cuda").manual_seed(3))
+    o.backward(do)
+    torch.cuda.synchronize()
+    # oracle on a subset of the (batch, head) pairs: every batch element that has a special role + a spread of heads
+    atol, rtol = TOL[dtype]
+    pairs = [(0, 0), (1, 1), (B - 1, H - 1), (B // 2, H // 3), (2 % B, 5 % H)]
+    for (b, h) in pairs:
+        mk = None if mask is None else _npf(mask[b:b + 1]).astype(bool)
+        ro, inv_l = O.attention_forward_stats(_npf(q[b:b + 1, h:h + 1]), _npf(k[b:b + 1, h:h + 1]), _npf(v[b:b + 1, h:h + 1]),
+                                              mask=mk, scale=scale, groups=groups, l2norm_qk=True)
+        got = _npf(o[b:b + 1, h:h + 1])
+        vmax = np.abs(_npf(v[b, h])).max()
+        err = np.abs(got - ro) - rtol * np.abs(ro)
+        assert err.max() <= atol * vmax, f"(b,h)={(b, h)} max excess {err.max():.3e}"
+        assert np.isfinite(got).all()
+    if mask is not None:
+        assert o[1].abs().max().item() == 0.0                 # no valid key -> zeros (oracle: attention_forward_stats)
+    # gradients against the oracle's backward on one pair (they consume the wide kernel's O and inv_l)
+    b, h = pairs[2]
+    mk = None if mask is None else _npf(mask[b:b + 1]).astype(bool)
+    gq, gk, gv, _ = O.attention_backward(_npf(do[b:b + 1, h:h + 1]), _npf(q[b:b + 1, h:h + 1]), _npf(k[b:b + 1, h:h + 1]),
+                                         _npf(v[b:b + 1, h:h + 1]), mask=mk, scale=scale, groups=groups, l2norm_qk=True)
+    for name, got, ref in (("dq", q.grad[b:b + 1, h:h + 1], gq), ("dk", k.grad[b:b + 1, h:h + 1], gk), ("dv", v.grad[b:b + 1, h:h + 1], gv)):
+        rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
+        assert rel <= GRAD_REL[dtype], f"{name} rel-L2 {rel:.3e}"
+
+
+def _ref_slice(q, k, v, causal, scale):
+    q, k, v = q.float(), k.float(), v.float()
+    s = (torch.nn.functional.normalize(q, dim=-1) @ torch.nn.functional.normalize(k, dim=-1).t()) * scale
+    n, m = s.shape
+    if causal:
+        s = s.masked_fill(torch.ones(n, m, dtype=torch.bool, device=s.device).triu(m - n + 1), float("-inf"))
+    return torch.softmax(s, dim=-1) @ v
+
+
+WIDE_CAUSAL = [
+    # B, H, N,    M,    D,  dtype
+    (2, 8, 8192, 8192, 64, torch.bfloat16),
+    (2, 7, 8192, 8200, 32, torch.float16),      # M > N: causal offset (seq_len_diff) and a ragged key tail
+    (7, 8, 2048, 2048, 96, torch.bfloat16),
+    (8, 8, 2050, 2050, 96, torch.float16),      # ragged rows
+]
+
+
+@pytest.mark.parametrize("B,H,N,M,D,dtype", WIDE_CAUSAL)
+def test_wide_forward_causal_vs_f32_slices(B, H, N, M, D, dtype):
+    import flash_cosine_sim_attention_amd as F
+    MT = (N + 255) // 256
+    assert B * H * ((MT + 1) // 2) >= 224, "shape would not dispatch to the wide kernel"
+    q, k, v = _inputs(B, H, N, M, D, dtype, seed=N + D)
+    o = F.flash_cosine_sim_attention(q, k, v, causal=True)
+    assert torch.isfinite(o).all()
+    atol, rtol = TOL[dtype]
+    for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, 3)):
+        ref = _ref_slice(q[b, h], k[b, h], v[b, h], True, 8)
+        err = ((o[b, h].float() - ref).abs() - rtol * ref.abs()).max().item()
+        assert err <= atol * v[b, h].float().abs().max().item(), f"slice {(b, h)} excess {err:.3e}"
+    # rows of P sum to one (every row has at least one valid key when M >= N)
+    o1 = F.flash_cosine_sim_attention(q, k, torch.ones_like(v), causal=True)
+    assert (o1.float() - 1).abs().max().item() <= (2e-3 if dtype == torch.float16 else 8e-3)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Phase timing of the forward kernel's inner loop from the trace build (libfcsa_hip_trace.so, -DFCSA_TRACE).
+usage: FCSA_LIB=.../libfcsa_hip_trace.so python tools/trace_fwd.py [fwd|dkv|dq]"""
+import ctypes as C, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flash_cosine_sim_attention_amd as F
+from flash_cosine_sim_attention_amd import _lib
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+B, H, N, D = 4, 8, 4096, 64
+q, k, v = (torch.randn(B, H, N, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+do = torch.randn_like(q)
+for _ in range(20):
+    q.grad = k.grad = v.grad = None
+    F.flash_cosine_sim_attention(q, k, v, causal=True).backward(do)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (C.c_ulonglong * 128)()
+fn = getattr(lib, "fcsa_trace_read_" + which)
+fn.argtypes = [C.POINTER(C.c_ulonglong)]
+assert fn(buf) == 0
+names = {"fwd": ["P1 S0(t) | E1b(t-1) | V0 req, stage store", "P2 PV1(t-1) | E0a | stage loads", "P3 S1(t) | E0b | V1 req", "barrier", "P4 PV0(t) | E1a | K req"]}.get(which, [f"seg{i}" for i in range(7)])
+for w in range(4):
+    a = list(buf[32 * w:32 * w + 32])
+    it, total = a[12], a[13]
+    if it == 0: print("wave", w, "no iterations"); continue
+    seg = a[:len(names)]
+    print(f"wave {w}: unmasked tiles {it}, counted {sum(seg)} of kernel total {total} ticks ({100.0*sum(seg)/max(total,1):.1f}%), per tile {sum(seg)/it:.0f} ticks")
+    for n, s_ in zip(names, seg):
+        print(f"    {n:<36} {s_/it:8.1f} ticks/tile  {100.0*s_/max(sum(seg),1):5.1f}%")
