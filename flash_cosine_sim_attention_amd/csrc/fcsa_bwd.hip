@@ -477,9 +477,15 @@ static hipError_t set_lds_once(K kern, size_t lds, bool& done) {
   return e;
 }
 
-template <typename T, int D, bool BIAS>
-static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
-  constexpr int NW = 4, BM = 32 * NW;
+// 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
+static int tile_waves(int64_t batch_heads, int len, bool causal) {
+  const int MT = (len + 255) / 256;
+  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
+}
+
+template <typename T, int D, bool BIAS, int NW>
+static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
+  constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
@@ -491,8 +497,16 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
 }
 
 template <typename T, int D, bool BIAS>
-static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
-  constexpr int NW = 4, BNK = 32 * NW;
+static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
+  if constexpr (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES) {
+    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8>(p, s);
+  }
+  return launch_dq_nw<T, D, BIAS, 4>(p, s);
+}
+
+template <typename T, int D, bool BIAS, int NW>
+static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
+  constexpr int BNK = 32 * NW;
   constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : 64;   // wide rows (16-bit D >= 96, f32 D >= 64): halve the staged tile (VGPR budget)
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
@@ -502,6 +516,14 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
+}
+
+template <typename T, int D, bool BIAS>
+static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
+  if constexpr (D * Traits<T>::ES <= FCSA_DKV_2W_BYTES) {
+    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
+  }
+  return launch_dkv_nw<T, D, BIAS, 4>(p, s);
 }
 
 template <typename T, int D> static hipError_t launch_dq_t(const BwdParams& p, hipStream_t s) {

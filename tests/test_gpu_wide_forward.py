@@ -47,9 +47,28 @@ WIDE_SMALL = [
 
 @pytest.mark.parametrize("B,H,N,M,D,dtype,use_mask,groups,scale", WIDE_SMALL)
 def test_wide_forward_matches_oracle(B, H, N, M, D, dtype, use_mask, groups, scale):
+    assert B * H * ((N + 255) // 256) >= 224, "shape would not dispatch to the wide kernel"
+    _many_heads_vs_oracle(B, H, N, M, D, dtype, use_mask, groups, scale, causal=False)
+
+
+# Causal with many small heads: the narrow kernels in their 8-waves-per-workgroup form (forward, dQ, dK/dV), which
+# the launchers choose when 256-row / 256-key workgroups still cover the chip.
+EIGHT_WAVE_CAUSAL = [
+    (8, 28, 300, 300, 64, torch.bfloat16, 1, 8),
+    (8, 28, 260, 300, 64, torch.float16, 1, 8),       # M > N: causal offset
+    (16, 16, 200, 200, 32, torch.bfloat16, 2, 10),
+    (6, 40, 257, 257, 16, torch.float16, 1, 8),
+]
+
+
+@pytest.mark.parametrize("B,H,N,M,D,dtype,groups,scale", EIGHT_WAVE_CAUSAL)
+def test_eight_wave_causal_matches_oracle(B, H, N, M, D, dtype, groups, scale):
+    _many_heads_vs_oracle(B, H, N, M, D, dtype, False, groups, scale, causal=True)
+
+
+def _many_heads_vs_oracle(B, H, N, M, D, dtype, use_mask, groups, scale, causal):
     import flash_cosine_sim_attention_amd as F
     from oracle import cosine_sim_oracle as O
-    assert B * H * ((N + 255) // 256) >= 224, "shape would not dispatch to the wide kernel"
     q, k, v = _inputs(B, H, N, M, D, dtype, seed=B * 1000 + N)
     mask = None
     if use_mask:
@@ -58,7 +77,7 @@ def test_wide_forward_matches_oracle(B, H, N, M, D, dtype, use_mask, groups, sca
         mask[:, 0] = True
         mask[1, :] = False                     # one batch element without any valid key: rows must come out 0
     q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
-    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups)
+    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups, causal=causal)
     do = torch.randn(o.shape, device="cuda", dtype=dtype, generator=torch.Generator(device="cuda").manual_seed(3))
     o.backward(do)
     torch.cuda.synchronize()
@@ -68,7 +87,7 @@ def test_wide_forward_matches_oracle(B, H, N, M, D, dtype, use_mask, groups, sca
     for (b, h) in pairs:
         mk = None if mask is None else _npf(mask[b:b + 1]).astype(bool)
         ro, inv_l = O.attention_forward_stats(_npf(q[b:b + 1, h:h + 1]), _npf(k[b:b + 1, h:h + 1]), _npf(v[b:b + 1, h:h + 1]),
-                                              mask=mk, scale=scale, groups=groups, l2norm_qk=True)
+                                              mask=mk, scale=scale, groups=groups, l2norm_qk=True, causal=causal)
         got = _npf(o[b:b + 1, h:h + 1])
         vmax = np.abs(_npf(v[b, h])).max()
         err = np.abs(got - ro) - rtol * np.abs(ro)
@@ -80,7 +99,7 @@ def test_wide_forward_matches_oracle(B, H, N, M, D, dtype, use_mask, groups, sca
     b, h = pairs[2]
     mk = None if mask is None else _npf(mask[b:b + 1]).astype(bool)
     gq, gk, gv, _ = O.attention_backward(_npf(do[b:b + 1, h:h + 1]), _npf(q[b:b + 1, h:h + 1]), _npf(k[b:b + 1, h:h + 1]),
-                                         _npf(v[b:b + 1, h:h + 1]), mask=mk, scale=scale, groups=groups, l2norm_qk=True)
+                                         _npf(v[b:b + 1, h:h + 1]), mask=mk, scale=scale, groups=groups, l2norm_qk=True, causal=causal)
     for name, got, ref in (("dq", q.grad[b:b + 1, h:h + 1], gq), ("dk", k.grad[b:b + 1, h:h + 1], gk), ("dv", v.grad[b:b + 1, h:h + 1], gv)):
         rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
         assert rel <= GRAD_REL[dtype], f"{name} rel-L2 {rel:.3e}"
