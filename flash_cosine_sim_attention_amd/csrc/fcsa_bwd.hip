@@ -36,6 +36,9 @@
 #include "fcsa_kernels.h"
 
 namespace fcsa {
+#ifdef FCSA_TRACE
+__device__ unsigned long long g_trace_dkv[128];
+#endif
 
 // =============================================================================================
 // dQ kernel
@@ -260,7 +263,7 @@ template <typename T, int D, int BMQ, bool MASKED, bool BIAS>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col) {
+                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col, Trace& ts) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
@@ -284,6 +287,7 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), vf[kk], dp);
+    FCSA_STAMP(ts, 2 + 3 * ib);
 
     f32x16 pr;
 #pragma unroll
@@ -303,11 +307,13 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     SecondB<T> pp, pd;
     pp.prep(pr);
     pd.prep(s);
+    FCSA_STAMP(ts, 3 + 3 * ib);
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
       dv[db] = second_mma<T, D>(dv[db], dot, 32 * ib, db, pp, fa);
       dk[db] = second_mma<T, D>(dk[db], qt, 32 * ib, db, pd, fa);
     }
+    FCSA_STAMP(ts, 4 + 3 * ib);
   }
 }
 
@@ -335,6 +341,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   const int b = bh / p.H, h = bh % p.H;
   const int npass = (p.causal && (KT - 1 - pt) != pt) ? 2 : 1;
   const int diff = p.M - p.N;
+  Trace ts;
+  ts.reset();
+#ifdef FCSA_TRACE
+  const unsigned long long trace_t0 = trace_now();
+#endif
   for (int pass = 0; pass < npass; ++pass) {
   const int kt = p.causal ? (pass == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
   const int n0 = kt * BNK;
@@ -435,17 +446,23 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       const char* cur = smem + par * BUF_B;
       char* nxt = smem + (par ^ 1) * BUF_B;
       const bool more = t + 1 < QT;
+      FCSA_STAMP(ts, 0);
       if (more) load_tile(t + 1);
+      FCSA_STAMP(ts, 1);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
       if constexpr (MASKED) {
         const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
-        if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col);
+        if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
       } else {
-        dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col);
+        dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
       }
+      FCSA_STAMP(ts, 8);
       if (more) store_tile(nxt);
+      FCSA_STAMP(ts, 9);
       __syncthreads();
+      FCSA_STAMP(ts, 10);
+      if constexpr (!MASKED) ts.close(10);
     }
   };
   run(std::true_type{}, t0, t_m);
@@ -466,7 +483,18 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     store_row_tile<T, D>(dvrow, dv, 1.f, fa.hi, p.dv_f32 != 0);
   }
   }   // pass
+#ifdef FCSA_TRACE
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_dkv + 32 * wave, trace_now() - trace_t0);
+#endif
 }
+
+#ifdef FCSA_TRACE
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_dkv(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_dkv), sizeof(unsigned long long) * 128);
+}
+namespace fcsa {
+#endif
 
 // ---------------------------------------------------------------------------------------------
 template <typename K>
@@ -507,7 +535,9 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
 template <typename T, int D, bool BIAS, int NW>
 static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BNK = 32 * NW;
-  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : 64;   // wide rows (16-bit D >= 96, f32 D >= 64): halve the staged tile (VGPR budget)
+  // staged query tile: 32 rows for wide feature rows (16-bit D >= 96, f32 D >= 64: VGPR budget of the staging registers),
+  // else 64; 128 in the 8-wave form (one workgroup per CU: the LDS is there, and half the barriers per key tile: -4.5%)
+  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : (NW == 8 ? 128 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);

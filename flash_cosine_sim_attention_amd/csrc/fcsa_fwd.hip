@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   }
   }   // pass
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
 #endif
 }
 
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
     }
   }   // pass
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
 #endif
 }
 
