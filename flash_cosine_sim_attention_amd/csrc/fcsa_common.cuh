@@ -60,6 +60,12 @@ template <> struct Traits<BF16> {
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
+  // Same MFMA with the accumulator pinned in AGPRs (inline asm): for accumulators no VALU instruction touches inside
+  // the loop, next to MFMAs whose results must stay in VGPRs (build flag -amdgpu-mfma-vgpr-form).  The compiler does
+  // not see an MFMA here: whoever READS such an accumulator outside asm must first let the pipe drain (mfma_drain()).
+  static FCSA_DEV void mfma32_agpr(const u32x4& a, const u32x4& b, f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  }
   static FCSA_DEV uint32_t pack2(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(uint32_t, v);
@@ -78,6 +84,9 @@ template <> struct Traits<F16> {
   static constexpr int ES = 2;
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static FCSA_DEV void mfma32_agpr(const u32x4& a, const u32x4& b, f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
   static FCSA_DEV uint32_t pack2(float a, float b) {
     f16x2 v = {(_Float16)a, (_Float16)b};
@@ -102,6 +111,9 @@ template <> struct Traits<F32> {
     return c;
   }
 };
+
+// wait states between the last mfma32_agpr and the first compiler-generated read of its accumulator (16-pass worst case)
+FCSA_DEV void mfma_drain() { asm volatile("s_nop 15\n s_nop 15" ::: "memory"); }
 
 // row index (0..31) of accumulator register r for lane half hi
 FCSA_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -439,6 +451,12 @@ FCSA_DEV unsigned long long trace_now() { unsigned long long v; asm volatile("s_
 struct Trace { FCSA_DEV void reset() {} FCSA_DEV void close(int) {} };
 #define FCSA_STAMP(ts, k) ((void)0)
 #endif
+
+// Issue slots of the slot-scheduled kernels (fwd2, dkv2): one MFMA + a fixed share of the VALU work + at most a couple
+// of memory instructions per slot, fenced so that hipcc's scheduler keeps exactly this program order.
+#define FCSA_FENCE() __builtin_amdgcn_sched_barrier(0)
+// items [m*N/S, (m+1)*N/S) of N items spread over S slots
+#define FCSA_SHARE(m, S, N, i) for (int i = (m) * (N) / (S); i < ((m) + 1) * (N) / (S); ++i)
 
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (2^x, quarter rate)
 

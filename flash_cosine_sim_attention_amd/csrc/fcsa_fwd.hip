@@ -431,9 +431,6 @@ FCSA_DEV void soft2(const f32x16& s, uint32_t wm, SecondB<T>& pb, float& lr, int
   lr = Traits<T>::add_pair(u, lr);
 }
 
-#define FCSA_FENCE() __builtin_amdgcn_sched_barrier(0)
-// items [m*N/S, (m+1)*N/S) of N items spread over S slots
-#define FCSA_SHARE(m, S, N, i) for (int i = (m) * (N) / (S); i < ((m) + 1) * (N) / (S); ++i)
 
 template <typename T, int D, bool MASKED, typename StageStore, typename StageLoad, typename Mid>
 FCSA_DEV void fwd2_tile(const char* vt, const char* knext, u32x4 (&kf)[2][TileGeom<D, 2>::KS], const FragAddr<T, D>& fa,
