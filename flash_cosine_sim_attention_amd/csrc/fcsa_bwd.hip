@@ -496,329 +496,6 @@ extern "C" int fcsa_trace_read_dkv(unsigned long long* out) {
 namespace fcsa {
 #endif
 
-// =============================================================================================
-// Wide dK / dV kernel (16-bit types, no bias, D <= 64): every wave owns 64 keys = two 32-key blocks that share each
-// Q / dO fragment (two MFMAs per LDS fragment read; the narrow kernel issues 32 LDS instructions per 16 MFMAs).
-// Slot-scheduled like fwd2_kernel (one fenced issue slot per MFMA).  Per 32-row query block ib:
-//
-//     G1  dP(ib)    | exp / pack of key block 0 of ib | Q row + aux requests of ib+1
-//     G2  S(ib+1)   | exp / pack of key block 1 of ib | dO^T requests of ib
-//     G3  dV(ib)    | dS = P (dP - delta), pack       | Q^T requests of ib
-//     G4  dK(ib)    |                                 | dO row requests of ib+1
-//
-// The per-row additive terms -- log2 of the normaliser for S, -delta for dP -- enter through ONE extra k-step of the S and
-// dP chains: an "aux" fragment per row [lc_hi, lc_lo, nd_hi, nd_lo, 0...] (16-bit hi + lo split, |error| < 2^-16 |x|)
-// against the constant B operands [1,1,0,0,..] / [0,0,1,1,..].  That replaces 8 ds_read_b128 per block (16 here) by one.
-// Query tiles of 64 rows (two blocks) rotate through THREE LDS buffers, so one barrier per tile is enough although the
-// S chain of the next tile's first block runs before the last transposed reads of the current tile.
-// =============================================================================================
-template <typename T, int D> struct Dkv2State {
-  typedef TileGeom<D, 2> G;
-  f32x16 dp[2];                                // dP - delta [key block]
-  SecondB<T> pp[2], pd[2];                     // packed P and dS [key block]
-  u32x4 qrow[G::KS], dorow[G::KS];             // row fragments in flight (S of the next block / dP of this block)
-  u32x4 dot_tr[G::DB][2], q_tr[G::DB][2];      // transposed fragments in flight [feature block][16-row step]
-};
-
-template <typename T, int D, bool MASKED, typename Extra>
-FCSA_DEV void dkv2_block(const char* qt_cur, const char* dot_cur, int rb_cur,
-                         const char* qt_nxt, const char* dot_nxt, const char* aux_nxt_tile, int rb_nxt,
-                         f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], const u32x4& aux_cur, u32x4& aux_nxt, Dkv2State<T, D>& st,
-                         const u32x4 (&kf)[2][TileGeom<D, 2>::KS], const u32x4 (&vf)[2][TileGeom<D, 2>::KS],
-                         const u32x4& b_s, const u32x4& b_dp,
-                         f32x16 (&dk)[2][TileGeom<D, 2>::DB], f32x16 (&dv)[2][TileGeom<D, 2>::DB],
-                         const FragAddr<T, D>& fa, const FragAddr<T, 16>& fax, const uint32_t (&w)[2], Trace& ts, int sb, Extra&& extra) {
-  typedef TileGeom<D, 2> G;
-  typedef Traits<T> TR;
-  constexpr int NS = 2 * (G::KS + 1);    // MFMAs of the S / dP groups (aux k-step included)
-  constexpr int NPV = 4 * G::DB;         // MFMAs of the dV / dK groups
-  f32x16 zero;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-  // two logits of key block kb: exp, (mask), keep P in f32 for dS, pack for dV
-  auto exp2chunk = [&](int kb, int c) {
-    float e0 = fast_exp2(s_cur[kb][2 * c]), e1 = fast_exp2(s_cur[kb][2 * c + 1]);
-    if constexpr (MASKED) {
-      e0 = ((w[kb] >> crow(2 * c, 0)) & 1u) ? e0 : 0.f;
-      e1 = ((w[kb] >> crow(2 * c + 1, 0)) & 1u) ? e1 : 0.f;
-    }
-    s_cur[kb][2 * c] = e0;
-    s_cur[kb][2 * c + 1] = e1;
-    st.pp[kb].v[c >> 2][c & 3] = TR::pack2(e0, e1);
-  };
-  FCSA_FENCE();
-  // ---- G1: dP(ib) | exp of key block 0 | Q row + aux requests of the next block
-#pragma unroll
-  for (int m = 0; m < NS; ++m) {
-    const int kk = m >> 1, kb = m & 1;
-    st.dp[kb] = TR::mfma32(kk < G::KS ? st.dorow[kk < G::KS ? kk : 0] : aux_cur, kk < G::KS ? vf[kb][kk < G::KS ? kk : 0] : b_dp,
-                           kk == 0 ? zero : st.dp[kb]);
-    FCSA_SHARE(m, NS, 8, c) exp2chunk(0, c);
-    FCSA_SHARE(m, NS, G::KS + 1, f) {
-      if (f < G::KS) st.qrow[f < G::KS ? f : 0] = fa.row_frag(qt_nxt, rb_nxt, f);
-      else aux_nxt = fax.row_frag(aux_nxt_tile, rb_nxt, 0);
-    }
-    extra(1, m);
-    FCSA_FENCE();
-  }
-  FCSA_STAMP(ts, sb + 1);
-  // ---- G2: S(ib+1) | exp of key block 1 | dO^T requests
-#pragma unroll
-  for (int m = 0; m < NS; ++m) {
-    const int kk = m >> 1, kb = m & 1;
-    s_nxt[kb] = TR::mfma32(kk < G::KS ? st.qrow[kk < G::KS ? kk : 0] : aux_nxt, kk < G::KS ? kf[kb][kk < G::KS ? kk : 0] : b_s,
-                           kk == 0 ? zero : s_nxt[kb]);
-    FCSA_SHARE(m, NS, 8, c) exp2chunk(1, c);
-    FCSA_SHARE(m, NS, 2 * G::DB, f) st.dot_tr[f >> 1][f & 1] = fa.tr_frag(dot_cur, rb_cur + 16 * (f & 1), f >> 1);
-    extra(2, m);
-    FCSA_FENCE();
-  }
-  FCSA_STAMP(ts, sb + 2);
-  // ---- G3: dV(ib) | dS = P (dP - delta), pack | Q^T requests
-#pragma unroll
-  for (int m = 0; m < NPV; ++m) {
-    const int ks = m / (2 * G::DB), db = (m >> 1) % G::DB, kb = m & 1;
-    TR::mfma32_agpr(st.dot_tr[db][ks], st.pp[kb].v[ks], dv[kb][db]);
-    FCSA_SHARE(m, NPV, 16, c) {
-      const int b2 = c >> 3, cc = c & 7;
-      st.pd[b2].v[cc >> 2][cc & 3] = TR::pack2(s_cur[b2][2 * cc] * st.dp[b2][2 * cc], s_cur[b2][2 * cc + 1] * st.dp[b2][2 * cc + 1]);
-    }
-    FCSA_SHARE(m, NPV, 2 * G::DB, f) st.q_tr[f >> 1][f & 1] = fa.tr_frag(qt_cur, rb_cur + 16 * (f & 1), f >> 1);
-    extra(3, m);
-    FCSA_FENCE();
-  }
-  FCSA_STAMP(ts, sb + 3);
-  // ---- G4: dK(ib) | dO row requests of the next block
-#pragma unroll
-  for (int m = 0; m < NPV; ++m) {
-    const int ks = m / (2 * G::DB), db = (m >> 1) % G::DB, kb = m & 1;
-    TR::mfma32_agpr(st.q_tr[db][ks], st.pd[kb].v[ks], dk[kb][db]);
-    FCSA_SHARE(m, NPV, G::KS, f) st.dorow[f] = fa.row_frag(dot_nxt, rb_nxt, f);
-    extra(4, m);
-    FCSA_FENCE();
-  }
-}
-
-template <typename T, int D, int NW>
-__global__ void __launch_bounds__(NW * 64, 1) bwd_dkv2_kernel(const BwdParams p) {
-  typedef TileGeom<D, 2> G;
-  typedef TileGeom<16, 2> GX;                   // aux rows: 32 bytes (chunk 0 = the four aux values, chunk 1 = zeros)
-  typedef Traits<T> TR;
-  static_assert(TR::ES == 2, "16-bit types only");
-  constexpr int KW = 64, BNK = KW * NW, NT = NW * 64, BMQ = 64;
-  constexpr int TILE_B = BMQ * G::ROWB;
-  constexpr int BUF_B = 2 * TILE_B + BMQ * GX::ROWB;             // Q tile | dO tile | aux rows
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][BUF_B]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  FragAddr<T, D> fa;
-  fa.init(lane);
-  FragAddr<T, 16> fax;
-  fax.init(lane);
-
-  const int KT = (p.M + BNK - 1) / BNK;
-  const int PT = p.causal ? (KT + 1) / 2 : KT;
-  int bh, pt;
-  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
-  const int b = bh / p.H, h = bh % p.H;
-  const int npass = (p.causal && (KT - 1 - pt) != pt) ? 2 : 1;
-  const int diff = p.M - p.N;
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
-  const u32x4 z4 = {0u, 0u, 0u, 0u};
-  u32x4 b_s = z4, b_dp = z4;                    // B operands of the aux k-step: k-slots 0,1 (S) / 2,3 (dP) of half 0
-  if (fa.hi == 0) { b_s[0] = TR::kOne2; b_dp[1] = TR::kOne2; }
-  const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
-  const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
-  const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
-  const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
-  Stager<T, D, BMQ, NT> sq, sdo;
-  sq.init(p.q.sn, tid);
-  sdo.init(p.d_out.sn, tid);
-  constexpr int PER = Stager<T, D, BMQ, NT>::PER;
-  Trace ts;
-  ts.reset();
-#ifdef FCSA_TRACE
-  const unsigned long long trace_t0 = trace_now();
-#endif
-
-  for (int pass = 0; pass < npass; ++pass) {
-    const int kt = p.causal ? (pass == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
-    const int n0 = kt * BNK;
-    const int nw = n0 + wave * KW;                        // first key of this wave
-    const int QT = (p.N + BMQ - 1) / BMQ;
-    int t0 = 0;
-    if (p.causal) t0 = max(0, n0 - diff) / BMQ;
-
-    // K, V fragments of this lane's two keys (B operands of S = Q K^T and dP = dO V^T), kept for the whole loop
-    u32x4 kf[2][G::KS], vf[2][G::KS];
-    uint32_t kmask[2];
-    int jk[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int j = nw + 32 * kb + (lane & 31);
-      jk[kb] = j;
-      const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
-      const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j * p.v.sn;
-#pragma unroll
-      for (int kk = 0; kk < G::KS; ++kk) {
-        kf[kb][kk] = z4;
-        vf[kb][kk] = z4;
-        if (j < p.M) {
-          kf[kb][kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + fa.hi) * 16);
-          if (!p.q_scaled) kf[kb][kk] = scale_frag<T>(kf[kb][kk], p.c1);
-          vf[kb][kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + fa.hi) * 16);
-        }
-      }
-      bool key_ok = j < p.M;
-      if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
-      kmask[kb] = key_ok ? 0xffffffffu : 0u;
-    }
-    f32x16 dk[2][G::DB], dv[2][G::DB];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[kb][db][r] = 0.f; dv[kb][db][r] = 0.f; }
-
-    // ---- staging: Q / dO chunks through registers, the aux row by the first BMQ threads
-    float lc_r = 0.f, dl_r = 0.f;
-    bool row_ok = false;
-    auto load_aux = [&](int t) {           // raw loads only
-      if (tid < BMQ) {
-        const int i = min(t * BMQ + tid, p.N - 1);
-        lc_r = invl_row[i];
-        dl_r = delta_row[i];
-        row_ok = t * BMQ + tid < p.N;
-      }
-    };
-    auto store_aux = [&](char* buf) {
-      if (tid < BMQ) {
-        // rows beyond N: lc = -1e4 makes P exactly 0 there (finite, so its hi / lo split is finite too)
-        const float lc = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -1e4f;
-        const float nd = row_ok ? -dl_r : 0.f;
-        const float lch = TR::lo(TR::pack2(lc, 0.f)), ndh = TR::lo(TR::pack2(nd, 0.f));
-        u32x4 c0 = {TR::pack2(lch, lc - lch), TR::pack2(ndh, nd - ndh), 0u, 0u};
-        char* ax = buf + 2 * TILE_B;
-        *reinterpret_cast<u32x4*>(ax + GX::off(tid, 0)) = c0;
-        *reinterpret_cast<u32x4*>(ax + GX::off(tid, 1)) = z4;
-      }
-    };
-    auto rows_of = [&](int t) { return t < QT ? p.N - t * BMQ : 0; };      // 0 -> zero-record descriptor
-
-    int bi = 0;                                   // LDS buffer of the current tile (0..2)
-    if (t0 < QT) {
-      sq.load(qbase + (int64_t)t0 * BMQ * p.q.sn, p.q.sn, rows_of(t0));
-      sdo.load(dobase + (int64_t)t0 * BMQ * p.d_out.sn, p.d_out.sn, rows_of(t0));
-      load_aux(t0);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) on ALL paths (see fwd_kernel)
-    f32x16 sA[2], sB[2];
-    u32x4 auxA = z4, auxB = z4;
-    Dkv2State<T, D> st;
-    if (t0 < QT) {
-      sq.store(smem, tid);
-      sdo.store(smem + TILE_B, tid);
-      store_aux(smem);
-      sq.load(qbase + (int64_t)(t0 + 1) * BMQ * p.q.sn, p.q.sn, rows_of(t0 + 1));
-      sdo.load(dobase + (int64_t)(t0 + 1) * BMQ * p.d_out.sn, p.d_out.sn, rows_of(t0 + 1));
-      load_aux(t0 + 1);
-    }
-    __syncthreads();
-    if (t0 < QT) {     // pipeline prologue: S of the first block, dO rows of the first block
-      f32x16 zero;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < G::KS; ++kk) st.qrow[kk] = fa.row_frag(smem, 0, kk);
-      auxA = fax.row_frag(smem + 2 * TILE_B, 0, 0);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        sA[kb] = zero;
-#pragma unroll
-        for (int kk = 0; kk < G::KS; ++kk) sA[kb] = TR::mfma32(st.qrow[kk], kf[kb][kk], sA[kb]);
-        sA[kb] = TR::mfma32(auxA, b_s, sA[kb]);
-      }
-#pragma unroll
-      for (int kk = 0; kk < G::KS; ++kk) st.dorow[kk] = fa.row_frag(smem + TILE_B, 0, kk);
-    }
-
-    // query tiles [t0, t_m) need masking for THIS wave, tiles [t_m, QT) do not (wave-uniform split, see bwd_dkv_kernel)
-    int t_m = QT;
-    if (p.mask == nullptr && n0 + BNK <= p.M) {
-      t_m = t0;
-      if (p.causal) t_m = min(QT, max(t0, (nw + KW - 1 - diff + BMQ - 1) / BMQ));
-    }
-    auto run = [&](auto masked_tag, int t_begin, int t_end) {
-      constexpr bool MASKED = decltype(masked_tag)::value;
-      for (int t = t_begin; t < t_end; ++t) {
-        const int i0 = t * BMQ;
-        const char* cur = smem + bi * BUF_B;
-        const int bn = bi == 2 ? 0 : bi + 1;
-        char* nxt = smem + bn * BUF_B;
-        uint32_t w0[2] = {0xffffffffu, 0xffffffffu}, w1[2] = {0xffffffffu, 0xffffffffu};
-        if constexpr (MASKED) {
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            w0[kb] = kmask[kb] & (ge_mask(jk[kb] - diff - (i0 + 4 * fa.hi)) | ncm);
-            w1[kb] = kmask[kb] & (ge_mask(jk[kb] - diff - (i0 + 32 + 4 * fa.hi)) | ncm);
-          }
-        }
-        FCSA_STAMP(ts, 0);
-        // block 0 (rows 0..31 of this tile); next block = rows 32..63 of the same tile.  Stage stores of tile t+1 ride in G3 / G4.
-        dkv2_block<T, D, MASKED>(cur, cur + TILE_B, 0, cur, cur + TILE_B, cur + 2 * TILE_B, 32, sA, sB, auxA, auxB, st, kf, vf, b_s, b_dp,
-                                 dk, dv, fa, fax, w0, ts, 0, [&](int g, int m) {
-          if (g == 3) { FCSA_SHARE(m, 4 * G::DB, PER, x) sq.store_one(nxt, tid, x); }
-          if (g == 4) { FCSA_SHARE(m, 4 * G::DB, PER, x) sdo.store_one(nxt + TILE_B, tid, x); }
-        });
-        FCSA_STAMP(ts, 4);
-        store_aux(nxt);
-        __syncthreads();                 // tile t+1 is visible; every read of tile t-1 (the buffer tile t+2 will take) has returned
-        FCSA_STAMP(ts, 5);
-        // block 1 (rows 32..63); next block = rows 0..31 of tile t+1.  Stage loads of tile t+2 ride in G3 / G4.
-        const __amdgpu_buffer_rsrc_t qd = Stager<T, D, BMQ, NT>::descriptor(qbase + (int64_t)(t + 2) * BMQ * p.q.sn, p.q.sn, rows_of(t + 2));
-        const __amdgpu_buffer_rsrc_t dd = Stager<T, D, BMQ, NT>::descriptor(dobase + (int64_t)(t + 2) * BMQ * p.d_out.sn, p.d_out.sn, rows_of(t + 2));
-        dkv2_block<T, D, MASKED>(cur, cur + TILE_B, 32, nxt, nxt + TILE_B, nxt + 2 * TILE_B, 0, sB, sA, auxB, auxA, st, kf, vf, b_s, b_dp,
-                                 dk, dv, fa, fax, w1, ts, 5, [&](int g, int m) {
-          if (g == 3) { FCSA_SHARE(m, 4 * G::DB, PER, x) sq.load_one(qd, x); }
-          if (g == 4) { FCSA_SHARE(m, 4 * G::DB, PER, x) sdo.load_one(dd, x); }
-        });
-        load_aux(t + 2);
-        FCSA_STAMP(ts, 9);
-        if constexpr (!MASKED) ts.close(9);
-        bi = bn;
-      }
-    };
-    run(std::true_type{}, t0, t_m);
-    run(std::false_type{}, t_m, QT);
-    __syncthreads();      // the next pass restages buffer 0 while slower waves may still read their last tile
-    mfma_drain();         // dk / dv were accumulated by asm MFMAs the compiler does not know about
-
-    const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int j = jk[kb];
-      if (j < p.M) {
-        char* dkrow = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)j * p.dk.sn;
-        char* dvrow = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)j * p.dv.sn;
-        if (p.rk != nullptr) {
-          const char* xrow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
-          store_row_tile_l2norm_bwd<T, D>(dkrow, dk[kb], kmul, fa.hi, xrow, 1.f,
-                                          p.rk + (((int64_t)b * p.H + h) * p.M + j) * p.G, p.lgm, p.norm_eps);
-        } else {
-          store_row_tile<T, D>(dkrow, dk[kb], kmul, fa.hi, p.dk_f32 != 0);
-        }
-        store_row_tile<T, D>(dvrow, dv[kb], 1.f, fa.hi, p.dv_f32 != 0);
-      }
-    }
-  }   // pass
-#ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_dkv + 32 * wave, trace_now() - trace_t0);
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t set_lds_once(K kern, size_t lds, bool& done) {
@@ -871,26 +548,8 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, int D>
-static hipError_t launch_dkv2(const BwdParams& p, hipStream_t s) {
-  constexpr int NW = 4, BNK = 64 * NW, BMQ = 64;
-  const int KT = (p.M + BNK - 1) / BNK;
-  const int PT = p.causal ? (KT + 1) / 2 : KT;
-  const size_t lds = 3 * (2 * BMQ * TileGeom<D, 2>::ROWB + BMQ * TileGeom<16, 2>::ROWB);
-  auto kern = bwd_dkv2_kernel<T, D, NW>;
-  static bool attr_set = false;
-  if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
-  return hipGetLastError();
-}
-
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
-#ifndef FCSA_FORCE_NARROW_DKV      // (A/B measurement builds only)
-  if constexpr (Traits<T>::ES == 2 && !BIAS && (D == 32 || D == 64)) {
-    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv2<T, D>(p, s);      // >= 224 workgroups of 256 keys
-  }
-#endif
   if constexpr (D * Traits<T>::ES <= FCSA_DKV_2W_BYTES) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
   }

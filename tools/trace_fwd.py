@@ -16,10 +16,10 @@ for _ in range(20):
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (C.c_ulonglong * 128)()
-fn = getattr(lib, "fcsa_trace_read_" + ("dkv" if which == "dkv2" else which))
+fn = getattr(lib, "fcsa_trace_read_" + which)
 fn.argtypes = [C.POINTER(C.c_ulonglong)]
 assert fn(buf) == 0
-names = {"fwd": ["P1 S0(t) | E1b(t-1) | V0 req, stage store", "P2 PV1(t-1) | E0a | stage loads", "P3 S1(t) | E0b | V1 req", "barrier", "P4 PV0(t) | E1a | K req"], "dkv": ["issue loads (tile t+1)", "ib0: S + dP chains (8 MFMA, frags JIT)", "ib0: exp / dS / pack", "ib0: dV + dK (8 MFMA, tr frags JIT)", "ib1: S + dP", "ib1: exp / dS / pack", "ib1: dV + dK", "-", "stage store", "barrier"], "dkv2": ["b0 G1 dP | exp kb0 | Q,aux req", "b0 G2 S(next) | exp kb1 | dO^T req", "b0 G3 dV | dS,pack | Q^T req | stage st", "b0 G4 dK | dO req | stage st", "aux store + barrier", "b1 G1", "b1 G2", "b1 G3 (+stage loads)", "b1 G4 (+stage loads)"]}.get(which, [f"seg{i}" for i in range(7)])
+names = {"fwd": ["P1 S0(t) | E1b(t-1) | V0 req, stage store", "P2 PV1(t-1) | E0a | stage loads", "P3 S1(t) | E0b | V1 req", "barrier", "P4 PV0(t) | E1a | K req"], "dkv": ["issue loads (tile t+1)", "ib0: S + dP chains (8 MFMA, frags JIT)", "ib0: exp / dS / pack", "ib0: dV + dK (8 MFMA, tr frags JIT)", "ib1: S + dP", "ib1: exp / dS / pack", "ib1: dV + dK", "-", "stage store", "barrier"]}.get(which, [f"seg{i}" for i in range(7)])
 for w in range(4):
     a = list(buf[32 * w:32 * w + 32])
     it, total = a[12], a[13]
