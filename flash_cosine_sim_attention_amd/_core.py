@@ -68,6 +68,23 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~10 us per call,
+    a third of a small forward)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == (dev.index if dev.index is not None else 0) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def _canonicalise(q, k, v, mask, attn_bias, attn_bias_batch_dim, causal):
     if not (q.is_cuda and k.is_cuda and v.is_cuda):
         raise RuntimeError("flash_cosine_sim_attention_amd: q, k, v must be GPU tensors (HIP kernels only, no CPU fallback)")
@@ -133,7 +150,7 @@ def attention_forward(q, k, v, mask=None, attn_bias=None, attn_bias_batch_dim=Fa
         raise ValueError(f"groups ({groups}) must divide the head dimension ({D})")
     q4, k4, v4 = _prep(q4), _prep(k4), _prep(v4)
     dev, dt = q.device, q.dtype
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         o = torch.empty((B, H, N, D), device=dev, dtype=dt)
         inv_l = torch.empty((B, H, N), device=dev, dtype=torch.float32) if need_backward else None
         qn = kn = rq = rk = None
@@ -170,7 +187,7 @@ def attention_backward(d_out: torch.Tensor, s: Saved, q_shape, k_shape, v_shape,
     if do4.dtype != dt:
         do4 = do4.to(dt)
     do4 = _prep(do4)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         dq = torch.empty((B, H, N, D), device=dev, dtype=dt)
         dk = torch.empty((B, Hk, M, D), device=dev, dtype=dt)
         dv = torch.empty((B, Hk, M, D), device=dev, dtype=dt)
@@ -198,7 +215,7 @@ def l2norm_device(t: torch.Tensor, groups: int = 1) -> torch.Tensor:
     D = shape[-1]
     t3 = _prep(t.reshape(1, 1, -1, D) if t.dim() < 4 else t.reshape(-1, shape[-3], shape[-2], D))
     out = torch.empty(t3.shape, device=t.device, dtype=t.dtype)
-    with torch.cuda.device(t.device):
+    with _on_device(t.device):
         x = _tensor4(t3)
         _lib.check(lib.fcsa_l2norm(_DTYPES[t.dtype], t3.shape[0], t3.shape[1], t3.shape[2], D, groups,
                                    C.byref(x), out.data_ptr(), None, _stream_ptr(t.device)), "fcsa_l2norm")
