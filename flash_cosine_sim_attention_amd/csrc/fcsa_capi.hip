@@ -47,6 +47,9 @@ int check_problem(const fcsa_problem& p) {
   if (p.l2norm_qk) {
     if (p.groups < 1 || p.dim_head % p.groups != 0)
       return fail(FCSA_ERR_INVALID_ARG, "groups (%d) must divide dim_head (%d)", p.groups, p.dim_head);
+    if (p.scale * (float)p.groups > 87.f)
+      return fail(FCSA_ERR_UNSUPPORTED, "scale * groups = %g > 87: exp of the logit range leaves f32 (saved row sums)",
+                  (double)(p.scale * (float)p.groups));
   } else if (p.groups != 1) {
     return fail(FCSA_ERR_INVALID_ARG, "groups must be 1 when l2norm_qk is 0");
   }
@@ -91,8 +94,20 @@ fcsa::View contiguous_view(void* p, int64_t heads, int64_t len, int64_t d, int e
 //             f16's NORMAL range even for large scale (with the reference's shift, scale = 16 puts exp(-16)
 //             = 1e-7 into f16 subnormals and the output error grows 10x).
 //       bf16 / f32 (8-bit exponent): shift = max(scale, scale*groups - 40); equals the reference for groups = 1.
+// A static shift only works while the whole logit range [-scale*groups, +scale*groups] fits the exponent range of the type
+// P~ is rounded to.  Real rows peak far below the theoretical bound once groups > 1 (found by the fuzz test: f16,
+// groups >= 4, scale >= 8 underflowed every P~ of a row to 0; the reference's shift = scale overflows there instead).
+// Beyond the safe range the forward kernel finds each row's max logit first and shifts by that ("dynamic"); the saved
+// inv_l then uses shift 0, i.e. it is 1 / sum_j exp(S_ij), which stays inside f32 for scale*groups <= 87.
+bool dynamic_shift(const fcsa_problem& p) {
+  if (!p.l2norm_qk) return false;
+  const float bound = p.scale * (float)p.groups;
+  return p.dtype == FCSA_F16 ? bound > 11.f : bound > 60.f;
+}
+
 float exponent_shift(const fcsa_problem& p) {
   if (!p.l2norm_qk) return p.scale;
+  if (dynamic_shift(p)) return 0.f;
   const float bound = p.scale * (float)p.groups;
   if (p.dtype == FCSA_F16) return bound - 10.f;
   return bound - 40.f > p.scale ? bound - 40.f : p.scale;
@@ -101,6 +116,7 @@ float exponent_shift(const fcsa_problem& p) {
 // Row-sum clamp: the reference clamps l at 1e-10 (cu:83, cu:1239) with shift = scale; with another shift the
 // same clamp in the reference's units is 1e-10 * exp(scale - shift) (kept inside f32's normal range).
 float rowsum_eps(const fcsa_problem& p) {
+  if (dynamic_shift(p)) return 1e-30f;          // row sums are >= 1 there (the max element contributes exp(0))
   float e = 1e-10f * expf(p.scale - exponent_shift(p));
   if (!(e > 1e-37f)) e = 1e-37f;
   if (e > 1e30f) e = 1e30f;
@@ -285,6 +301,7 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.bias_c = kLog2e;
   fp.l_eps = rowsum_eps(p);
   fp.q_scaled = p.l2norm_qk ? 1 : 0;
+  fp.dyn = dynamic_shift(p) ? 1 : 0;
   return timed("fwd", "forward", s, [&] { return fcsa::launch_forward(p.dtype, p.dim_head, fp, s); });
 }
 

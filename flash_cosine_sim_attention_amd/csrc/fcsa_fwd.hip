@@ -77,7 +77,7 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
 template <typename T, int D, bool MASKED, bool BIAS, typename Mid>
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
-                       float& l, f32x16& lacc, const FwdParams& p, uint64_t word, uint32_t ncm, int i, int j0, int diff,
+                       float& l, f32x16& lacc, const FwdParams& p, float c2row, uint64_t word, uint32_t ncm, int i, int j0, int diff,
                        const char* bias_row, Trace& ts, Mid&& mid) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -95,7 +95,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     constexpr int MFMA = 0x8, VALU = 0x2 | 0x400, DSR = 0x100;
     f32x16 s0, s1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = -p.c2; s1[r] = -p.c2; }   // exponent shift as the accumulator's initial value
+    for (int r = 0; r < 16; ++r) { s0[r] = -c2row; s1[r] = -c2row; }   // exponent shift (static, or this row's max) as the accumulator's initial value
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s0 = TR::mfma32(kf[0][kk], qf[kk], s0);
     u32x4 vf0[G::DB][2], vf1[G::DB][2];
@@ -165,7 +165,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[jb][r] = -p.c2;
+      for (int r = 0; r < 16; ++r) s[jb][r] = -c2row;
 #pragma unroll
       for (int kk = 0; kk < G::KS; ++kk) s[jb] = TR::mfma32(kf[jb][kk], qf[kk], s[jb]);
     }
@@ -196,7 +196,9 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
   }
 }
 
-template <typename T, int D, int NW, bool BIAS>
+// DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
+// the main loop then starts the S accumulators from -max instead of the static shift; inv_l is saved for shift 0.
+template <typename T, int D, int NW, bool BIAS, bool DYN>
 __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) fwd_kernel(const FwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -266,6 +268,45 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   if constexpr (BIAS)
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
+
+  float c2row = p.c2;
+  if constexpr (DYN) {
+    // plain (unpipelined) pass: this path only serves logit ranges no static exponent window can hold
+    float m2 = -INFINITY;
+    Stager<T, D, BN, NT> s1;
+    s1.init(p.k.sn, tid);
+    for (int t = 0; t < nt; ++t) {
+      const int j0 = t * BN;
+      s1.load(kbase + (int64_t)j0 * p.k.sn, p.k.sn, p.M - j0);
+      __syncthreads();                     // readers of the previous tile are done
+      s1.store(smem, tid);
+      __syncthreads();
+      const int key = min(j0 + lane, p.M - 1);
+      const uint64_t word = __ballot((j0 + lane) < p.M && (mrow == nullptr || mrow[key] != 0));
+      if (p.causal && j0 > mw + 31 + diff) continue;       // wave-uniform; the barriers above are still executed
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const uint32_t w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(smem, 32 * jb, kk), qf[kk], s);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = s[r];
+          if constexpr (BIAS) {
+            const int j = min(j0 + 32 * jb + 4 * fa.hi + crow(r, 0), p.M - 1);
+            x += (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
+          }
+          m2 = ((w >> crow(r, 0)) & 1u) ? fmaxf(m2, x) : m2;
+        }
+      }
+    }
+    m2 = fmaxf(m2, __shfl_xor(m2, 32, 64));
+    c2row = m2 == -INFINITY ? 0.f : m2;     // rows without a valid key: any finite shift (their P~ are all masked to 0)
+    __syncthreads();
+  }
 
   // Pipeline (per 64-key tile t; two LDS buffers, one register staging set, ONE barrier per tile):
   //   top of t : staging registers (tile t+1, loaded during t-1) -> LDS buffer (t+1)&1; global loads of tile t+2
@@ -353,7 +394,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
       if (!PREFETCH_K && !skip) request_k(vcur - TILE_B);
       if (skip) mid();
-      else fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, word, ncm, i, j0, diff, bias_row, ts, mid);
+      else fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid);
       FCSA_STAMP(ts, 10);
       if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only
     }
@@ -367,7 +408,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
   const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift
   if (i < p.N) {
-    if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = inv;
+    // saved for the backward in the GLOBAL shift convention (DYN: shift 0, i.e. 1 / sum_j exp(S_ij))
+    if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = DYN ? inv * __builtin_amdgcn_exp2f(-c2row) : inv;
     char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
     store_row_tile<T, D>(orow, o, inv, fa.hi, false);
   }
@@ -731,13 +773,13 @@ static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
 
-template <typename T, int D, bool BIAS, int NW>
+template <typename T, int D, bool BIAS, int NW, bool DYN>
 static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K tile + V tile) of 64 keys
-  auto kern = fwd_kernel<T, D, NW, BIAS>;
+  auto kern = fwd_kernel<T, D, NW, BIAS, DYN>;
   static bool attr_set = false;                  // per instantiation; the attribute is sticky
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -750,16 +792,17 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
+  if (p.dyn) return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);      // dynamic-shift path: one (4-wave) form
   if constexpr (D * Traits<T>::ES <= 128) {      // the two-waves-per-SIMD instantiations
-    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8>(p, s);
+    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   }
-  return launch_fwd_nw<T, D, BIAS, 4>(p, s);
+  return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
 }
 
 template <typename T, int D>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
   if constexpr (Traits<T>::ES == 2 && D <= 96) {       // D = 128: the pipeline state does not fit 512 registers
-    if (p.bias == nullptr && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
+    if (p.bias == nullptr && !p.dyn && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
   }
   return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);
 }
