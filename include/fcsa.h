@@ -20,7 +20,11 @@
  *                            (reference: 3-D k/v unsqueezed at cu:1656-1660, is_single_head_kv cu:1679)
  *   mask                   : [B, M] bytes, non-zero = keep   (cu:1208-1211; torch.bool storage)
  *   attn_bias              : [Hb, N, M], Hb == H (per head) or Hb == B when bias_batch_dim (cu:1168, cu:1214)
- *   inv_l                  : [B, H, N] float32 = 1 / max(rowsum, 1e-10)   (cu:1236-1242)
+ *   inv_l                  : [B, H, N] float32 = 1 / max(rowsum, eps): the row sums are taken with a library-chosen
+ *                            constant exponent shift.  l2norm_qk == 0: shift = scale and eps = 1e-10, the
+ *                            reference's values exactly (cu:1216, cu:1236-1242).  l2norm_qk == 1: opaque to the
+ *                            caller (forward and backward of this library agree on it); the clamp is the
+ *                            reference's rescaled to the shift, except in the wide-range regime below.
  *   Tensors are described by a base pointer and ELEMENT strides for the three leading
  *   dims; the feature dim must be contiguous (stride 1) and every row 16-byte aligned.
  *   A merged batch-heads query ([BH, N, D], cu:1647-1654) is passed as B = BH, H = 1.
@@ -79,7 +83,13 @@ typedef struct fcsa_problem {
                                flash_cosine_sim_attention.py:320-321); 0: q,k used as given
                                (exactly the reference extension's contract) */
   int32_t groups;           /* l2norm groups (flash_cosine_sim_attention.py:50-55); 1 if !l2norm_qk */
-  float   scale;            /* logits = scale * qh.kh ; exponent shift = -scale (cu:1216) */
+  float   scale;            /* logits = scale * qh.kh ; reference exponent shift = -scale (cu:1216).
+                               With l2norm_qk the logit range is +-scale*groups.  scale*groups must be <= 87
+                               (FCSA_ERR_UNSUPPORTED beyond: exp of the range leaves float32).  Where no constant
+                               shift fits the range into the exponent of the type P is rounded to (float16:
+                               scale*groups > 11, else > 60) the forward kernel shifts every row by its own max logit
+                               and normalises it exactly (no 1e-10 clamp: in exp(S - scale) units that clamp would
+                               attenuate or zero rows there; the reference kernel itself overflows / zeroes) */
 } fcsa_problem;
 
 /* State the fused-l2norm forward saves for backward (all caller-allocated, contiguous):
