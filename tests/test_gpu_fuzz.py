@@ -23,7 +23,7 @@ FWD_TOL = {"f16": (5e-3, 2.0 ** -10), "bf16": (2e-2, 2.0 ** -7), "f32": (2e-5, 2
 GRAD_TOL = {"f16": 3e-3, "bf16": 1.2e-2, "f32": 2e-5}
 
 
-def _configs(n_cases=48, seed=20260926):
+def _configs(n_cases=96, seed=20260926):
     rng = np.random.RandomState(seed)
     out = []
     for c in range(n_cases):
