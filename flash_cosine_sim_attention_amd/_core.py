@@ -160,11 +160,18 @@ def attention_forward(q, k, v, mask=None, attn_bias=None, attn_bias_batch_dim=Fa
             if need_backward:
                 rq = torch.empty((B, H, N, groups), device=dev, dtype=torch.float32)
                 rk = torch.empty((B, Hk, M, groups), device=dev, dtype=torch.float32)
+        prob = _problem(dt, dims, causal, bias_batch, l2norm_qk, groups, scale)
+        ws = None
+        if not causal and B * H * N <= 16384:          # only grids that cannot fill the chip ever split (saves the call otherwise)
+            ws_bytes = int(lib.fcsa_forward_workspace_bytes(C.byref(prob)))
+            if ws_bytes:
+                ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         args = _lib.ForwardArgs(
-            _problem(dt, dims, causal, bias_batch, l2norm_qk, groups, scale),
+            prob,
             _tensor4(q4), _tensor4(k4), _tensor4(v4), _tensor4(o),
             _ptr(inv_l), _ptr(mask), _ptr(attn_bias),
             _lib.NormState(_ptr(qn), _ptr(kn), _ptr(rq), _ptr(rk)),
+            _ptr(ws), 0 if ws is None else ws.numel(),
             _stream_ptr(dev))
         _lib.check(lib.fcsa_forward(C.byref(args)), "fcsa_forward")
     out = o.squeeze(1) if merged else o                                                  # cu:1740-1741

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("FCSA_LIB") or os.path.join(_HERE, "libfcsa_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 FCSA_F32, FCSA_F16, FCSA_BF16 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Tensor(C.Structure):
@@ -38,7 +38,7 @@ class NormState(C.Structure):
 class ForwardArgs(C.Structure):
     _fields_ = [("p", Problem), ("q", Tensor), ("k", Tensor), ("v", Tensor), ("o", Tensor),
                 ("inv_l", C.c_void_p), ("mask", C.c_void_p), ("attn_bias", C.c_void_p),
-                ("norm", NormState), ("stream", C.c_void_p)]
+                ("norm", NormState), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
 
 
 class BackwardArgs(C.Structure):
@@ -53,7 +53,7 @@ class KernelStat(C.Structure):
                 ("max_ms", C.c_float)]
 
 
-EXPORTS = ("fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_l2norm", "fcsa_debug",
+EXPORTS = ("fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_forward_workspace_bytes", "fcsa_l2norm", "fcsa_debug",
            "fcsa_last_error", "fcsa_profile_enable", "fcsa_profile_collect")
 
 _lib = None
@@ -88,6 +88,8 @@ def load():
     lib.fcsa_backward.restype = C.c_int
     lib.fcsa_backward_workspace_bytes.argtypes = [C.POINTER(Problem)]
     lib.fcsa_backward_workspace_bytes.restype = C.c_size_t
+    lib.fcsa_forward_workspace_bytes.argtypes = [C.POINTER(Problem)]
+    lib.fcsa_forward_workspace_bytes.restype = C.c_size_t
     lib.fcsa_l2norm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcsa_l2norm.restype = C.c_int

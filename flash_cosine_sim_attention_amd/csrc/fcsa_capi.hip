@@ -230,7 +230,7 @@ int fcsa_debug(char* buf, size_t buf_bytes) {
   if (buf != nullptr && buf_bytes > 0) {
     snprintf(buf, buf_bytes,
              "libfcsa_hip abi=%d arch=gfx950 dtypes=f32,f16,bf16 dim_head=16,32,64,96,128 "
-             "kernels=l2norm,fwd(32x32x16 mfma, 128x64 tile),bwd_dq(128x64),bwd_dkv(128 keys x 64 rows),finalize",
+             "kernels=l2norm_pair,fwd(32 rows/wave),fwd2(64 rows/wave),fwd_split+combine,bwd_dq,bwd_dkv,finalize",
              FCSA_ABI_VERSION);
   }
   return FCSA_ABI_VERSION;
@@ -254,6 +254,29 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
   np.out_scale = 1.f;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return timed("l2norm", "l2norm", s, [&] { return fcsa::launch_l2norm(dtype, np, s); });
+}
+
+// Split-key forward: how many workgroups share one row tile's key range.  Only where the 128-row tiles cannot fill the
+// chip (< 128 workgroups for 256 CUs), the problem is not causal (key ranges of a causal row tile are short and uneven),
+// the static exponent shift applies (partials with a common shift add up exactly) and every split keeps >= 512 keys.
+static int forward_splits(const fcsa_problem& p) {
+  if (p.causal || dynamic_shift(p)) return 1;
+  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
+  if (wgs <= 0 || wgs >= 128) return 1;
+  int64_t s = (256 + wgs - 1) / wgs;
+  if (s > 16) s = 16;
+  if (s > p.k_len / 512) s = p.k_len / 512;
+  return s >= 2 ? (int)s : 1;
+}
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+size_t fcsa_forward_workspace_bytes(const fcsa_problem* p) {
+  if (p == nullptr || p->batch <= 0 || p->heads <= 0 || p->q_len <= 0 || p->dim_head <= 0) return 0;
+  const int s = forward_splits(*p);
+  if (s <= 1) return 0;
+  const size_t rows = (size_t)s * p->batch * p->heads * p->q_len;
+  return align256(rows * p->dim_head * 4) + align256(rows * 4);
 }
 
 int fcsa_forward(const fcsa_forward_args* a) {
@@ -302,6 +325,17 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.l_eps = rowsum_eps(p);
   fp.q_scaled = p.l2norm_qk ? 1 : 0;
   fp.dyn = dynamic_shift(p) ? 1 : 0;
+  fp.splits = 1; fp.ws_o = nullptr; fp.ws_l = nullptr;
+  if (a->workspace != nullptr && a->attn_bias == nullptr) {
+    const int sp = forward_splits(p);
+    const size_t need = fcsa_forward_workspace_bytes(&p);
+    if (sp > 1 && a->workspace_bytes >= need && (reinterpret_cast<uintptr_t>(a->workspace) & 255) == 0) {
+      const size_t rows = (size_t)sp * p.batch * p.heads * p.q_len;
+      fp.splits = sp;
+      fp.ws_o = static_cast<float*>(a->workspace);
+      fp.ws_l = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + align256(rows * p.dim_head * 4));
+    }
+  }
   return timed("fwd", "forward", s, [&] { return fcsa::launch_forward(p.dtype, p.dim_head, fp, s); });
 }
 

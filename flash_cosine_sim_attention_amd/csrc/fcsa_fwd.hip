@@ -221,7 +221,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
   const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
-  const int diff = p.M - p.N;                     // cu:1097 seq_len_diff
+  // split-key launches (gridDim.y = p.splits > 1, never causal / bias / dynamic shift): this workgroup sees the keys
+  // [k_lo, k_lo + Mk) only and writes un-normalised partials; everything below works on that sub-problem
+  int k_lo = 0, Mk = p.M;
+  if (p.splits > 1) {
+    const int tps = ((p.M + BN - 1) / BN + p.splits - 1) / p.splits;      // 64-key tiles per split
+    k_lo = (int)blockIdx.y * tps * BN;
+    Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
+  }
+  const int diff = p.M - p.N - k_lo;              // cu:1097 seq_len_diff (in the sub-problem's key numbering)
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const int i = mw + (lane & 31);                 // this lane's query row
 
   // key tiles this workgroup needs
-  int last_key = p.M - 1;
+  int last_key = Mk - 1;
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
@@ -262,9 +270,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 #pragma unroll
   for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
 
-  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
-  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
-  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
+  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M + k_lo : nullptr;
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   if constexpr (BIAS)
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
@@ -277,12 +285,12 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     s1.init(p.k.sn, tid);
     for (int t = 0; t < nt; ++t) {
       const int j0 = t * BN;
-      s1.load(kbase + (int64_t)j0 * p.k.sn, p.k.sn, p.M - j0);
+      s1.load(kbase + (int64_t)j0 * p.k.sn, p.k.sn, Mk - j0);
       __syncthreads();                     // readers of the previous tile are done
       s1.store(smem, tid);
       __syncthreads();
-      const int key = min(j0 + lane, p.M - 1);
-      const uint64_t word = __ballot((j0 + lane) < p.M && (mrow == nullptr || mrow[key] != 0));
+      const int key = min(j0 + lane, Mk - 1);
+      const uint64_t word = __ballot((j0 + lane) < Mk && (mrow == nullptr || mrow[key] != 0));
       if (p.causal && j0 > mw + 31 + diff) continue;       // wave-uniform; the barriers above are still executed
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
@@ -326,9 +334,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(kt, 32 * jb, kk);
   };
   if (nt > 0) {
-    sk.load(kbase, p.k.sn, p.M);
-    sv.load(vbase, p.v.sn, p.M);
-    if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
+    sk.load(kbase, p.k.sn, Mk);
+    sv.load(vbase, p.v.sn, Mk);
+    if (mrow) mb = lane < Mk ? mrow[lane] : (uint8_t)0;
   }
   // Every prologue load (Q fragments, first tile, mask byte) is complete here on the real path; say so on ALL
   // paths.  Otherwise hipcc's waitcnt model keeps the Q loads pending along the no-tile path, the loop-header
@@ -339,8 +347,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     sk.store(smem, tid);
     sv.store(smem + TILE_B, tid);
     if (nt > 1) {
-      sk.load(kbase + (int64_t)BN * p.k.sn, p.k.sn, p.M - BN);
-      sv.load(vbase + (int64_t)BN * p.v.sn, p.v.sn, p.M - BN);
+      sk.load(kbase + (int64_t)BN * p.k.sn, p.k.sn, Mk - BN);
+      sv.load(vbase + (int64_t)BN * p.v.sn, p.v.sn, Mk - BN);
     }
   }
   __syncthreads();
@@ -352,7 +360,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   // loops execute one barrier per tile, so waves of one workgroup may sit in different loops)
   int t_split = 0;
   if (!BIAS && mrow == nullptr) {
-    t_split = p.M / BN;                                                // tail tile (j0 + BN > M) is masked
+    t_split = Mk / BN;                                                 // tail tile (j0 + BN > Mk) is masked
     if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);  // needs (t+1)*BN - 1 <= mw + diff
     t_split = min(t_split, nt);
   }
@@ -367,10 +375,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       uint64_t word = 0;
       if constexpr (MASKED) {
         // consume the mask byte loaded one tile ago BEFORE issuing new loads (its wait then covers nothing else)
-        word = __ballot((j0 + lane) < p.M && mb != 0);                  // valid keys of this tile
+        word = __ballot((j0 + lane) < Mk && mb != 0);                   // valid keys of this tile
         if (mrow && t + 1 < nt) {
           const int key = j0 + BN + lane;
-          mb = key < p.M ? mrow[key] : (uint8_t)0;
+          mb = key < Mk ? mrow[key] : (uint8_t)0;
         }
       }
       if (t + 1 < nt) {
@@ -379,8 +387,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       }
       FCSA_STAMP(ts, 1);
       if (t + 2 < nt) {
-        sk.load(kbase + (int64_t)(j0 + 2 * BN) * p.k.sn, p.k.sn, p.M - (j0 + 2 * BN));
-        sv.load(vbase + (int64_t)(j0 + 2 * BN) * p.v.sn, p.v.sn, p.M - (j0 + 2 * BN));
+        sk.load(kbase + (int64_t)(j0 + 2 * BN) * p.k.sn, p.k.sn, Mk - (j0 + 2 * BN));
+        sv.load(vbase + (int64_t)(j0 + 2 * BN) * p.v.sn, p.v.sn, Mk - (j0 + 2 * BN));
       }
       FCSA_STAMP(ts, 2);
       auto mid = [&]() {
@@ -406,6 +414,14 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
   const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
+  if (p.splits > 1) {     // un-normalised partial of this key range; fwd_combine_kernel sums, clamps and normalises
+    if (i < p.N) {
+      const int64_t prow = ((int64_t)blockIdx.y * p.B * p.H + bh) * p.N + i;
+      if (fa.hi == 0) p.ws_l[prow] = lt;
+      store_row_tile<T, D>(reinterpret_cast<char*>(p.ws_o + prow * D), o, 1.f, fa.hi, true);
+    }
+    continue;
+  }
   const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift
   if (i < p.N) {
     // saved for the backward in the GLOBAL shift convention (DYN: shift 0, i.e. 1 / sum_j exp(S_ij))
@@ -773,6 +789,45 @@ static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
 
+// Split-key forward, second step: O = (sum_s partial P~V) / max(sum_s partial l, eps), inv_l alike.  One thread per
+// (row, 8 features); the partials are a few MB and L2-resident.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) fwd_combine_kernel(const FwdParams p) {
+  constexpr int CH = D / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t rows = (int64_t)p.B * p.H * p.N;
+  if (idx >= rows * CH) return;
+  const int64_t row = idx / CH;
+  const int c = (int)(idx - row * CH);
+  float acc[8], lt = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int sidx = 0; sidx < p.splits; ++sidx) {
+    const int64_t prow = (int64_t)sidx * rows + row;
+    lt += p.ws_l[prow];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws_o + prow * D + 8 * c);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.ws_o + prow * D + 8 * c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b2[e]; }
+  }
+  const float inv = 1.f / fmaxf(lt, p.l_eps);
+  const int64_t bh = row / p.N;
+  const int i = (int)(row - bh * p.N);
+  const int b = (int)(bh / p.H), h = (int)(bh - (int64_t)b * p.H);
+  char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
+  if constexpr (Traits<T>::ES == 4) {
+    f32x4 x = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv}, y = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+    reinterpret_cast<f32x4*>(orow + 32 * c)[0] = x;
+    reinterpret_cast<f32x4*>(orow + 32 * c)[1] = y;
+  } else {
+    u32x4 u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = Traits<T>::pack2(acc[2 * e] * inv, acc[2 * e + 1] * inv);
+    *reinterpret_cast<u32x4*>(orow + 16 * c) = u;
+  }
+  if (c == 0 && p.inv_l != nullptr) p.inv_l[row] = inv;
+}
+
 template <typename T, int D, bool BIAS, int NW, bool DYN>
 static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
@@ -786,13 +841,19 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT), (unsigned)(p.splits > 1 ? p.splits : 1)), dim3(NW * 64), lds, s, p);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  if (p.splits > 1) {
+    const int64_t items = (int64_t)p.B * p.H * p.N * (D / 8);
+    hipLaunchKernelGGL((fwd_combine_kernel<T, D>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
+  }
   return hipGetLastError();
 }
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   if (p.dyn) return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);      // dynamic-shift path: one (4-wave) form
+  if (p.splits > 1) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);   // split-key path: 128-row tiles x key ranges
   if constexpr (D * Traits<T>::ES <= 128) {      // the two-waves-per-SIMD instantiations
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   }
@@ -802,7 +863,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
 template <typename T, int D>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
   if constexpr (Traits<T>::ES == 2 && D <= 96) {       // D = 128: the pipeline state does not fit 512 registers
-    if (p.bias == nullptr && !p.dyn && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
+    if (p.bias == nullptr && !p.dyn && p.splits <= 1 && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
   }
   return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);
 }

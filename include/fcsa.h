@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FCSA_ABI_VERSION 1
+#define FCSA_ABI_VERSION 2
 
 enum fcsa_status {
   FCSA_OK = 0,
@@ -113,6 +113,13 @@ typedef struct fcsa_forward_args {
   const uint8_t*  mask;          /* [B,M] contiguous or NULL */
   const void*     attn_bias;     /* [Hb,N,M] contiguous or NULL */
   fcsa_norm_state norm;
+  void*           workspace;     /* optional: >= fcsa_forward_workspace_bytes(&p) bytes, 256-byte aligned, or NULL.
+                                    With it, launches whose row tiles cannot fill the chip split the KEY range over
+                                    several workgroups (un-normalised partial (P~V, l) add up exactly -- there is no
+                                    running max to reconcile -- and a combine kernel normalises).  Without it the
+                                    result is the same, from fewer workgroups.  No reference counterpart (its grid is
+                                    row tiles only, cu:1714-1718). */
+  size_t          workspace_bytes;
   void*           stream;        /* hipStream_t */
 } fcsa_forward_args;
 
@@ -143,6 +150,9 @@ int fcsa_backward(const fcsa_backward_args* args);
 
 /* Scratch needed by fcsa_backward for this problem (delta, f32 gradient slabs). */
 size_t fcsa_backward_workspace_bytes(const fcsa_problem* p);
+
+/* Bytes of optional forward scratch that enable the split-key forward for this problem (0: never split). */
+size_t fcsa_forward_workspace_bytes(const fcsa_problem* p);
 
 /* Standalone grouped l2norm on device: the public l2norm_tensors (flash_cosine_sim_attention.py:57-65).
  * x [B,H,N,D] (strided) -> xn [B,H,N,D] contiguous, inv_norm [B,H,N,G] float32 (may be NULL). */

@@ -29,8 +29,8 @@ def _declared_functions():
 
 def test_exports_every_declared_symbol(lib):
     names = _declared_functions()
-    assert {"fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_l2norm", "fcsa_debug",
-            "fcsa_last_error"} <= set(names)
+    assert {"fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_forward_workspace_bytes", "fcsa_l2norm",
+            "fcsa_debug", "fcsa_last_error"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fcsa.h but not exported"
     from flash_cosine_sim_attention_amd import _lib
@@ -78,7 +78,7 @@ def _problem(**kw):
 def _fwd_args(prob, mask=None):
     from flash_cosine_sim_attention_amd import _lib
     t = _lib.Tensor(0x1000, 1024, 512, 64)      # fake, never dereferenced: validation fails first
-    return _lib.ForwardArgs(prob, t, t, t, t, None, mask, None, _lib.NormState(None, None, None, None), None)
+    return _lib.ForwardArgs(prob, t, t, t, t, None, mask, None, _lib.NormState(None, None, None, None), None, 0, None)
 
 
 def test_validation_errors_without_gpu(lib):
@@ -125,9 +125,23 @@ def test_backward_workspace_formula(lib):
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + 2 * al(B * H * M * D * 4)
 
 
+def test_forward_workspace_formula(lib):
+    # split-key forward: only non-causal problems whose 128-row tiles cannot fill the chip, with >= 1024 keys
+    al = lambda x: (x + 255) // 256 * 256
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64)      # C4: 64 row tiles -> 4 splits
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(4 * 8 * 1024 * 64 * 4) + al(4 * 8 * 1024 * 4)
+    p = _problem(batch=4, heads=8, kv_heads=8, q_len=1024, k_len=1024, dim_head=64)      # C2: 256 row tiles
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64, causal=1)
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
+    p = _problem(batch=1, heads=2, kv_heads=2, q_len=8, k_len=4096, dim_head=128)        # 2 row tiles -> 8 splits of 512 keys
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(8 * 2 * 8 * 128 * 4) + al(8 * 2 * 8 * 4)
+    assert lib.fcsa_forward_workspace_bytes(None) == 0
+
+
 def test_debug_string(lib):
     buf = C.create_string_buffer(512)
-    assert lib.fcsa_debug(buf, 512) == 1
+    assert lib.fcsa_debug(buf, 512) == 2          # FCSA_ABI_VERSION
     assert b"gfx950" in buf.value and b"bf16" in buf.value
 
 

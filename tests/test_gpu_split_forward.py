@@ -1,0 +1,96 @@
+"""Split-key forward (fcsa_fwd.hip: fwd_kernel with gridDim.y = splits + fwd_combine_kernel; chosen by fcsa_capi.hip
+forward_splits when a non-causal problem's 128-row tiles cannot fill the chip and the caller passes the optional
+workspace): parity with the float64 oracle, forward and -- through the saved inv_l -- backward."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cosine_sim_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+FWD_TOL = {"f16": (5e-3, 2.0 ** -10), "bf16": (2e-2, 2.0 ** -7), "f32": (2e-5, 2e-5)}
+GRAD_TOL = {"f16": 3e-3, "bf16": 1.2e-2, "f32": 2e-5}
+
+CASES = [
+    # dtype, B, H, N,   M,    D,  mask,  single_kv, l2norm, groups
+    ("bf16", 1, 2, 40, 1500, 64, False, False, True, 1),      # 2 splits, ragged last split
+    ("f16", 1, 8, 300, 2100, 64, True, False, True, 1),       # key mask, 3 row tiles per head
+    ("bf16", 1, 4, 200, 2048, 64, False, False, True, 4),     # grouped l2norm (bf16: static shift up to scale * groups = 60)
+    ("f32", 1, 1, 8, 4096, 128, False, False, True, 1),       # 8 splits, f32 MFMA path
+    ("bf16", 2, 3, 129, 1100, 32, True, True, True, 1),       # single-headed K/V
+    ("f16", 1, 4, 64, 1024, 96, False, False, False, 1),      # reference contract: q, k already normalised
+    ("bf16", 1, 1, 1, 8192, 16, False, False, True, 1),       # one query row ("decode"), 16 splits
+]
+
+
+def _npf(t):
+    return t.detach().cpu().double().numpy()
+
+
+@pytest.mark.parametrize("dtype,B,H,N,M,D,use_mask,single_kv,l2norm,groups", CASES)
+def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups):
+    import flash_cosine_sim_attention_amd as F
+    from flash_cosine_sim_attention_amd import _core, _lib
+    dt = DT[dtype]
+    prob = _core._problem(dt, (B, H, 1 if single_kv else H, N, M, D), False, False, l2norm, groups, 8.0 if l2norm else 0.125)
+    assert _lib.load().fcsa_forward_workspace_bytes(C.byref(prob)) > 0, "case would not take the split-key path"
+    g = torch.Generator(device="cuda").manual_seed(N * 7 + M)
+    q = torch.randn((B, H, N, D), device="cuda", dtype=dt, generator=g)
+    kv_shape = (B, M, D) if single_kv else (B, H, M, D)
+    k = torch.randn(kv_shape, device="cuda", dtype=dt, generator=g)
+    v = torch.randn(kv_shape, device="cuda", dtype=dt, generator=g)
+    if not l2norm:
+        q, k = torch.nn.functional.normalize(q.float(), dim=-1).to(dt), torch.nn.functional.normalize(k.float(), dim=-1).to(dt)
+    mask = None
+    if use_mask:
+        mask = torch.rand((B, M), device="cuda", generator=g) > 0.4
+        mask[:, :3] = True
+        mask[:, 600:1100] = False            # a whole split (or most of it) without a valid key
+    q.requires_grad_(); k.requires_grad_(); v.requires_grad_()
+    scale = 8.0 if l2norm else 0.125
+    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups, l2norm_qk=l2norm)
+    do = torch.randn(o.shape, device="cuda", dtype=dt, generator=g)
+    o.backward(do)
+    torch.cuda.synchronize()
+    mk = None if mask is None else _npf(mask).astype(bool)
+    kw = dict(mask=mk, scale=scale, groups=groups, l2norm_qk=l2norm)
+    ro, _ = O.attention_forward_stats(_npf(q), _npf(k), _npf(v), **kw)
+    atol, rtol = FWD_TOL[dtype]
+    excess = (np.abs(_npf(o) - ro) - rtol * np.abs(ro)).max()
+    assert excess <= atol * max(np.abs(_npf(v)).max(), 1.0), f"forward excess {excess:.3e}"
+    rdq, rdk, rdv, _ = O.attention_backward(_npf(do), _npf(q), _npf(k), _npf(v), **kw)
+    for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
+        rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
+        assert rel <= GRAD_TOL[dtype], f"{name} rel-L2 {rel:.3e}"
+
+
+def test_split_and_unsplit_agree_through_the_c_abi():
+    """Same problem with and without the optional workspace: the C ABI promises the same result."""
+    from flash_cosine_sim_attention_amd import _core, _lib
+    lib = _lib.load()
+    B, H, N, M, D = 1, 4, 96, 3000, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q, k, v = (torch.randn(s, device="cuda", dtype=torch.bfloat16, generator=g) for s in ((B, H, N, D), (B, H, M, D), (B, H, M, D)))
+    outs = []
+    for use_ws in (False, True):
+        o = torch.empty_like(q)
+        inv_l = torch.empty((B, H, N), device="cuda", dtype=torch.float32)
+        qn, kn = torch.empty_like(q), torch.empty_like(k)
+        prob = _core._problem(q.dtype, (B, H, H, N, M, D), False, False, True, 1, 8.0)
+        nbytes = int(lib.fcsa_forward_workspace_bytes(C.byref(prob)))
+        assert nbytes > 0
+        ws = torch.empty((nbytes,), device="cuda", dtype=torch.uint8) if use_ws else None
+        args = _lib.ForwardArgs(prob, _core._tensor4(q), _core._tensor4(k), _core._tensor4(v), _core._tensor4(o), inv_l.data_ptr(),
+                                None, None, _lib.NormState(qn.data_ptr(), kn.data_ptr(), None, None),
+                                None if ws is None else ws.data_ptr(), 0 if ws is None else nbytes,
+                                torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.fcsa_forward(C.byref(args)), "fcsa_forward")
+        torch.cuda.synchronize()
+        outs.append((o.float(), inv_l.clone()))
+    (o0, l0), (o1, l1) = outs
+    assert (o0 - o1).abs().max().item() <= 2.0 ** -7 * o0.abs().max().item()      # one output ulp: the summation order differs
+    assert ((l0 - l1).abs() / l0.abs()).max().item() <= 1e-5
