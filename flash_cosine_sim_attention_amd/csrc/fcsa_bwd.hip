@@ -14,9 +14,12 @@
 //                    loop: S^T = K Q^T, dP^T = V dO^T, dS^T, dQ^T += K^T dS^T.
 //   bwd_dkv_kernel : key-row parallel.  K/V fragments of the wave's 32 keys stay in VGPRs; Q and dO
 //                    tiles stream through LDS; S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
-//                    Writes one [M, D] slab per (batch, q-head); with single-headed K/V the slabs are
+//                    Writes dk / dv per (batch, q-head); with single-headed K/V f32 slabs are
 //                    reduced over heads by the finalize kernel (fcsa_norm.hip) instead of the
 //                    reference's f32 atomics (cu:1613-1619).
+// Both kernels finish the l2norm backward in their epilogue (store_row_tile_l2norm_bwd) when the group size allows,
+// pair causal tiles (constant work per workgroup) and run with 4 or 8 waves per workgroup (8: tiles staged once per CU;
+// dkv then stages 128-row query tiles, half the barriers).
 //
 // 7 tile products instead of the reference's 5 (S and dP are recomputed in both kernels); results
 // are deterministic.  d_bias (optional path) is accumulated with f32 atomics like cu:1574-1576.

@@ -8,7 +8,9 @@
 // Decomposition (one workgroup = NW waves = 32*NW query rows; K/V tiles of BN = 64 keys):
 //   * each wave keeps its 32 query rows' Q fragments in VGPRs for the whole key loop
 //     (the reference re-reads the Q tile from global for every column tile, cu:1185-1189);
-//   * K and V tiles are staged global -> VGPR -> LDS, double buffered, one barrier per tile;
+//   * K and V tiles are staged global -> VGPR -> LDS (buffer loads), double buffered, one barrier per tile placed in
+//     the MIDDLE of the tile (after its last LDS read) so the next tile's K fragments are requested before the PV
+//     products (see the pipeline comment in fwd_kernel);
 //   * S^T = K Q^T on v_mfma_f32_32x32x16 (A = K rows via ds_read_b128, B = Q registers), so a
 //     lane owns ONE query (column) and 16 keys (rows) of each 32x32 block;
 //   * exp2 + masking stay in registers; P~ is packed to 16 bit in place and becomes the
@@ -23,6 +25,12 @@
 //   * the key loop is split in two SEQUENTIAL loops, first the tiles that need no masking, then the
 //     tiles that do (key mask / tail / causal diagonal).  Each loop has one straight-line body, so the
 //     accumulators never cross an if/else join (which costs dozens of register copies per tile).
+//
+// Variants chosen by launch_forward (all parity-tested through the normal dispatch):
+//   fwd_kernel<.., NW = 4 | 8, ..>  two 128-row workgroups per CU, or one 256-row workgroup when the grid still covers the chip
+//   fwd_kernel<.., DYN>             per-row exponent shift for logit ranges no constant shift can hold (first pass = row max)
+//   fwd_kernel, gridDim.y = splits  key range split over several workgroups + fwd_combine_kernel (grids that cannot fill the chip)
+//   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 96, 16 bit, no bias; see its header)
 #include <cstdlib>
 #include <type_traits>
 
