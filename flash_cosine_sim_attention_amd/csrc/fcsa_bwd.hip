@@ -41,6 +41,7 @@
 namespace fcsa {
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_dkv[128];
+__device__ unsigned long long g_trace_dq[128];
 #endif
 
 // =============================================================================================
@@ -107,13 +108,17 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
   }
 }
 
-template <typename T, int D, int NW, bool BIAS>
+// SUB = 64-key tiles per LDS stage: 1, or 2 in the 8-wave form (one workgroup per CU has the LDS for 128-key stages).  The
+// phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
+// halves that (the same change gave the dKV kernel 4.5 %).
+template <typename T, int D, int NW, bool BIAS, int SUB>
 __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
-  constexpr int TILE_B = BN * G::ROWB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+  constexpr int BN = 64, BM = 32 * NW, NT = NW * 64, BNS = BN * SUB;
+  constexpr int TILE_B = BN * G::ROWB;          // one 64-key tile of K or V
+  constexpr int HALF_B = SUB * TILE_B;          // K (or V) part of a stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K stage | V stage]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -130,6 +135,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
   const int diff = p.M - p.N;
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
+  Trace ts;
+  ts.reset();
+#ifdef FCSA_TRACE
+  const unsigned long long trace_t0 = trace_now();
+#endif
   for (int pass = 0; pass < npass; ++pass) {
   const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
@@ -185,22 +195,25 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     if (p.d_bias != nullptr && i < p.N) dbias_row = p.d_bias + boff;
   }
 
-  Stager<T, D, BN, NT> sk, sv;
+  // stages u = t / SUB of SUB 64-key tiles: loads of stage u+1 are issued at the first tile of stage u, stored after its last
+  // tile, one barrier per stage (double-buffered LDS)
+  Stager<T, D, BNS, NT> sk, sv;
   sk.init(p.k.sn, tid);
   sv.init(p.v.sn, tid);
   uint8_t mb = 1;
+  const int nst = (nt + SUB - 1) / SUB;
   if (nt > 0) {
     sk.load(kbase, p.k.sn, p.M);
     sv.load(vbase, p.v.sn, p.M);
     if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
     sk.store(smem, tid);
-    sv.store(smem + TILE_B, tid);
+    sv.store(smem + HALF_B, tid);
   }
   __syncthreads();
-  // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
+  // Every prologue load (Q / dO / K / V fragments, first stage) is complete on the real path; say so on ALL paths.
   // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never
   // clears that, and each iteration re-waits with vmcnt(0) at its first MFMA -- right after issuing the next
-  // tile's prefetch, which serialises the prefetch with the compute meant to hide it.
+  // stage's prefetch, which serialises the prefetch with the compute meant to hide it.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
   int t_split = 0;                                 // see fwd_kernel
@@ -214,33 +227,43 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     constexpr bool MASKED = decltype(masked_tag)::value;
     for (int t = t_begin; t < t_end; ++t) {
       const int j0 = t * BN;
-      const char* kcur = smem + (t & 1) * 2 * TILE_B;
-      const char* vcur = kcur + TILE_B;
-      char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
-      const bool more = t + 1 < nt;
+      const int u = t / SUB, sub = t % SUB;
+      const char* kcur = smem + (u & 1) * 2 * HALF_B + sub * TILE_B;
+      const char* vcur = kcur + HALF_B;
+      char* snxt = smem + ((u + 1) & 1) * 2 * HALF_B;
+      const bool more = u + 1 < nst;                       // another stage follows
+      const bool last_of_stage = sub == SUB - 1 || t + 1 >= nt;
+      FCSA_STAMP(ts, 0);
       uint64_t word = 0;
       if constexpr (MASKED) {     // consume the mask byte BEFORE issuing new loads (see fwd_kernel)
         word = __ballot((j0 + lane) < p.M && mb != 0);
-        if (mrow && more) {
+        if (mrow && t + 1 < nt) {
           const int key = j0 + BN + lane;
           mb = key < p.M ? mrow[key] : (uint8_t)0;
         }
       }
-      if (more) {
-        sk.load(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, p.M - (j0 + BN));
-        sv.load(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, p.M - (j0 + BN));
+      if (sub == 0 && more) {
+        sk.load(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, p.M - (u + 1) * BNS);
+        sv.load(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, p.M - (u + 1) * BNS);
       }
+      FCSA_STAMP(ts, 1);
       if constexpr (MASKED) {
         const bool skip = p.causal && (j0 > mw + 31 + diff);
         if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
       } else {
         dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, dbias_row);
       }
-      if (more) {
-        sk.store(knxt, tid);
-        sv.store(knxt + TILE_B, tid);
+      FCSA_STAMP(ts, 2);
+      if (last_of_stage) {                                 // workgroup-uniform
+        if (more) {
+          sk.store(snxt, tid);
+          sv.store(snxt + HALF_B, tid);
+        }
+        FCSA_STAMP(ts, 3);
+        __syncthreads();
       }
-      __syncthreads();
+      FCSA_STAMP(ts, 4);
+      if constexpr (!MASKED) ts.close(4);
     }
   };
   run(std::false_type{}, 0, t_split);
@@ -257,6 +280,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     }
   }
   }   // pass
+#ifdef FCSA_TRACE
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_dq + 32 * wave, trace_now() - trace_t0);
+#endif
 }
 
 // =============================================================================================
@@ -493,6 +519,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
 
 #ifdef FCSA_TRACE
 }  // namespace fcsa
+extern "C" int fcsa_trace_read_dq(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_dq), sizeof(unsigned long long) * 128);
+}
 extern "C" int fcsa_trace_read_dkv(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_dkv), sizeof(unsigned long long) * 128);
 }
@@ -519,8 +548,9 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;
-  auto kern = bwd_dq_kernel<T, D, NW, BIAS>;
+  constexpr int SUB = NW == 8 ? 2 : 1;
+  const size_t lds = 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K stage + V stage)
+  auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
   static bool attr_set = false;
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
