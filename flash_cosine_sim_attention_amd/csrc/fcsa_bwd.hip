@@ -31,6 +31,9 @@
 #ifndef FCSA_DKV_2W_BYTES
 #define FCSA_DKV_2W_BYTES 128
 #endif
+#ifndef FCSA_DKV_BMQ8
+#define FCSA_DKV_BMQ8 128      // staged query rows of the 8-wave dKV form
+#endif
 #ifndef FCSA_DQ_2W_BYTES
 #define FCSA_DQ_2W_BYTES 128
 #endif
@@ -570,7 +573,7 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BNK = 32 * NW;
   // staged query tile: 32 rows for wide feature rows (16-bit D >= 96, f32 D >= 64: VGPR budget of the staging registers),
   // else 64; 128 in the 8-wave form (one workgroup per CU: the LDS is there, and half the barriers per key tile: -4.5%)
-  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : (NW == 8 ? 128 : 64);
+  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);
