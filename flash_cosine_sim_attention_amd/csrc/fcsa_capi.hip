@@ -293,6 +293,7 @@ int fcsa_forward(const fcsa_forward_args* a) {
   const bool single = p.kv_heads == 1 && p.heads > 1;
 
   fcsa::FwdParams fp;
+  bool fuse_q = false;
   fp.q = view(a->q, es);
   fp.k = view(a->k, es, single);
   fp.v = view(a->v, es, single);
@@ -310,8 +311,15 @@ int fcsa_forward(const fcsa_forward_args* a) {
     nk.x = view(a->k, es); nk.xn = static_cast<char*>(n.kn); nk.inv_norm = n.rk;
     nk.B = p.batch; nk.H = p.kv_heads; nk.L = p.k_len;
     nk.out_scale = 1.f;
-    if (int rc = timed("l2norm", "l2norm(q,k)", s, [&] { return fcsa::launch_l2norm_pair(p.dtype, nq, nk, s); })) return rc;
-    fp.q = contiguous_view(n.qn, p.heads, p.q_len, p.dim_head, es);
+    // 16-bit types with group sizes of 8 * 2^k: q is normalised in the forward kernel's prologue (load_q_frags), which also
+    // writes qn / rq for the backward; only k takes the HBM pass.  Otherwise both go through the row kernel.
+    fuse_q = p.dtype != FCSA_F32 && fusable_groups(p);
+    if (fuse_q) {
+      if (int rc = timed("l2norm", "l2norm(k)", s, [&] { return fcsa::launch_l2norm(p.dtype, nk, s); })) return rc;
+    } else {
+      if (int rc = timed("l2norm", "l2norm(q,k)", s, [&] { return fcsa::launch_l2norm_pair(p.dtype, nq, nk, s); })) return rc;
+    }
+    if (!fuse_q) fp.q = contiguous_view(n.qn, p.heads, p.q_len, p.dim_head, es);
     fp.k = contiguous_view(n.kn, p.kv_heads, p.k_len, p.dim_head, es, single);
   }
   fp.inv_l = a->inv_l;
@@ -324,6 +332,10 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.bias_c = kLog2e;
   fp.l_eps = rowsum_eps(p);
   fp.q_scaled = p.l2norm_qk ? 1 : 0;
+  fp.q_raw = fuse_q ? 1 : 0;
+  fp.qn_out = fuse_q ? static_cast<char*>(a->norm.qn) : nullptr;
+  fp.rq_out = fuse_q ? a->norm.rq : nullptr;
+  fp.G = p.groups; fp.lgm = fuse_q ? log2_blocks_per_group(p) : 0; fp.norm_eps = 1e-12f;
   fp.dyn = dynamic_shift(p) ? 1 : 0;
   fp.splits = 1; fp.ws_o = nullptr; fp.ws_l = nullptr;
   if (a->workspace != nullptr && a->attn_bias == nullptr) {

@@ -204,6 +204,57 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
   }
 }
 
+// Q fragments of query row i (B operand of S^T = K Q^T): lane (i, hi) holds the 16-byte chunks 2*kk + hi, so the lane
+// pair of a row holds the whole row.  Three input forms:
+//   q_raw    : RAW q (fused l2norm, 16-bit types, group size 8 * 2^lgm).  The grouped l2norm (reference py:50-55,
+//              F.normalize eps 1e-12) is done here in registers: per-chunk sums of squares, one lane^32 add per k-step,
+//              r = 1 / max(||q_g||, eps), q^ * c1 rounded ONCE to the 16-bit type -- bit-identical to what l2norm_kernel
+//              writes -- and published (qn_out, rq_out) for the backward kernels.  Saves the separate HBM pass over q.
+//   q_scaled : c1 * q^ already (written by l2norm_kernel: f32, odd group sizes)
+//   else     : q^ as given (the reference extension's contract); c1 is folded in here
+template <typename T, int D>
+FCSA_DEV void load_q_frags(const FwdParams& p, int b, int h, int i, const FragAddr<T, D>& fa,
+                           u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS]) {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+#pragma unroll
+  for (int kk = 0; kk < G::KS; ++kk) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    qf[kk] = z;
+    if (i < p.N) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+  }
+  if constexpr (Traits<T>::ES == 2) {
+    if (p.q_raw) {
+      float pair[G::KS];
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) {
+        const float ss = dot_frag<T>(qf[kk], qf[kk]);
+        pair[kk] = p.lgm >= 1 ? xhalf_sum(ss) : ss;      // groups of >= 16 features contain both chunks of a k-step
+      }
+      const int sh = p.lgm >= 1 ? p.lgm - 1 : 0;         // k-steps per group = 1 << sh
+      const int64_t row = ((int64_t)b * p.H + h) * p.N + i;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < G::KS; ++k2) tot += ((k2 >> sh) == (kk >> sh)) ? pair[k2] : 0.f;
+        const float r = 1.f / fmaxf(sqrtf(tot), p.norm_eps);
+        qf[kk] = scale_frag<T>(qf[kk], r * p.c1);
+        if (i < p.N) {
+          const int c = 2 * kk + fa.hi;
+          *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];
+          if (p.rq_out != nullptr && (c & ((1 << p.lgm) - 1)) == 0) p.rq_out[row * p.G + (c >> p.lgm)] = r;
+        }
+      }
+      return;
+    }
+  }
+  if (!p.q_scaled) {
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) qf[kk] = scale_frag<T>(qf[kk], p.c1);
+  }
+}
+
 // DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
 // the main loop then starts the S accumulators from -max instead of the static shift; inv_l is saved for shift 0.
 template <typename T, int D, int NW, bool BIAS, bool DYN>
@@ -255,18 +306,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
-  // Q fragments (B operand of S^T = K Q^T): 16-byte chunk 2*kk + hi of row i
   u32x4 qf[G::KS];
-  {
-    const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
-#pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      qf[kk] = z;
-      if (i < p.N) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
-      if (!p.q_scaled) qf[kk] = scale_frag<T>(qf[kk], p.c1);     // reference-contract path: q^ given, fold c1 here
-    }
-  }
+  load_q_frags<T, D>(p, b, h, i, fa, qf);
 
   f32x16 o[G::DB];
 #pragma unroll
@@ -618,17 +659,7 @@ __global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
 
     u32x4 qf[2][G::KS];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int i = i0 + 32 * r;
-      const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
-#pragma unroll
-      for (int kk = 0; kk < G::KS; ++kk) {
-        u32x4 z = {0u, 0u, 0u, 0u};
-        qf[r][kk] = z;
-        if (i < p.N) qf[r][kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
-        if (!p.q_scaled) qf[r][kk] = scale_frag<T>(qf[r][kk], p.c1);
-      }
-    }
+    for (int r = 0; r < 2; ++r) load_q_frags<T, D>(p, b, h, i0 + 32 * r, fa, qf[r]);
     f32x16 o[2][G::DB];
 #pragma unroll
     for (int r = 0; r < 2; ++r)

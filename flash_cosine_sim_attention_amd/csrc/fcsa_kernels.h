@@ -24,6 +24,12 @@ struct FwdParams {
   float l_eps;              // clamp of the row sum: 1e-10 (cu:83) rescaled by exp(scale - shift)
   int q_scaled;             // 1: q already carries the factor c1 (fused l2norm writes c1 * q^); 0: the kernel applies it
   int dyn;                  // 1: per-row exponent shift (row max found by a first pass over K); c2 is 0 then
+  int q_raw;                // 1 (16-bit types, fusable groups): q is the RAW query; the kernel prologue does its grouped l2norm,
+                            //    folds c1 in, and publishes the saved state of the backward:
+  char* qn_out;             //    [B,H,N,D] contiguous c1 * q^ (dtype)
+  float* rq_out;            //    [B,H,N,G] 1 / max(||q_group||, eps), or nullptr when no backward follows
+  int G, lgm;               //    groups; log2(group size / 8)
+  float norm_eps;
   int splits;               // > 1: the key range is split over gridDim.y workgroups that write un-normalised partials
   float* ws_o;              // [splits][B*H][N][D] f32 partial P~V
   float* ws_l;              // [splits][B*H][N]    f32 partial row sums
