@@ -2,8 +2,9 @@
 (flash_cosine_sim_attention/__init__.py:1, flash_cosine_sim_attention.py:308-334).
 
 Differences from the reference, all inside the boundary:
-  * the (grouped) l2norm of q and k is FUSED into the op (library row kernel + saved inverse
-    norms) instead of two eager F.normalize passes outside the autograd.Function
+  * the (grouped) l2norm of q and k is FUSED into the op (q in the forward kernel's prologue, k in
+    a library row kernel, inverse norms saved; the l2norm backward in the dQ / dKV epilogues)
+    instead of two eager F.normalize passes outside the autograd.Function
     (flash_cosine_sim_attention.py:320-321), so `FlashCosineSimAttention.backward` returns
     gradients w.r.t. the RAW q, k;
   * GPU tensors only run on the hand-written gfx950 kernels; there is no silent fallback.
