@@ -37,6 +37,9 @@
 #ifndef FCSA_DQ_2W_BYTES
 #define FCSA_DQ_2W_BYTES 128
 #endif
+#ifndef FCSA_DKV_PIPE
+#define FCSA_DKV_PIPE 1        // software-pipelined dKV tile (16-bit types, no bias); 0 = the plain form, for A/B builds
+#endif
 
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
@@ -349,13 +352,138 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
   }
 }
 
+// Software-pipelined form of dkv_tile (16-bit types, no bias).  Two findings shape it (MI355X, C3, `tools/ab_libs.py`):
+//   * The plain form reads every A fragment right in front of the MFMA that consumes it; hipcc then funnels them through ONE
+//     register quad (ds_read_b128 v[4:7] -> s_waitcnt lgkmcnt(0) -> v_mfma, 16 times per 32x32 block).  Here every LDS
+//     request is issued one pipeline stage before its consumer:
+//         M1(ib) : S and dP chains from the row fragments requested during M2(ib-1)
+//         T(ib)  : the 4*DB transposed fragments of this block are requested right behind the M1 MFMAs ...
+//         X(ib)  : ... and land during exp / pack
+//         R(ib+1): the next block's row fragments are requested (their registers died in M1), interleaved with ...
+//         M2(ib) : ... the dV / dK products
+//   * LDS traffic, not the matrix pipe, bounds this kernel: with every LDS read stubbed out it runs in 80 us instead of 141.
+//     A third of that traffic were the per-query terms (log2-normaliser and -delta: 32 floats per lane per block, read as
+//     8 broadcast ds_read_b128 = 8 KiB per wave per block to seed the S / dP accumulators).  They now ride in on the MATRIX
+//     pipe: the staging thread of query row i splits lc_i and -delta_i into three 16-bit pieces each (hi + mid + lo: 24+
+//     bits) and stores them as two 16-byte chunks; lane (i, hi) of a block reads ONE chunk (hi = 0: lc pieces, hi = 1:
+//     -delta pieces) and that register quad is the A operand of one extra k-step for S (B = ones in the k-slots of the hi = 0
+//     half, zeros elsewhere) and one for dP (B = ones in the hi = 1 half): S = lc (x) 1 + Q K^T, dP = -delta (x) 1 + dO V^T.
+//     +2 MFMAs per block (18 instead of 16), -7 KiB of LDS reads per block (17 instead of 24), 32 registers freed.
+template <typename T, int D, int BMQ>
+struct DkvPipe {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  u32x4 qa[G::KS], da[G::KS];      // A operands of the next S / dP chains
+  u32x4 aux;                       // per-query terms of the next block (see above)
+
+  // aux_lane: byte offset of this lane's chunk inside a block's aux area = hi * BMQ * 16 + (lane & 31) * 16
+  FCSA_DEV void request(const char* qt, const char* dot, const char* auxs, int aux_lane, const FragAddr<T, D>& fa, int ib) {
+    aux = *reinterpret_cast<const u32x4*>(auxs + aux_lane + ib * 32 * 16);
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) { qa[kk] = fa.row_frag(qt, 32 * ib, kk); da[kk] = fa.row_frag(dot, 32 * ib, kk); }
+  }
+};
+
+// x -> three 16-bit pieces whose f32 sum reproduces x to >= 24 bits (k-slots 0..2 of an aux chunk; slots 3..7 are zero)
+template <typename T> FCSA_DEV u32x4 split3(float x) {
+  typedef Traits<T> TR;
+  if constexpr (TR::ES == 4) { u32x4 z = {0u, 0u, 0u, 0u}; return z; } else {
+  const uint32_t p0 = TR::pack2(x, 0.f);
+  const float r1 = x - TR::lo(p0);
+  const uint32_t p1 = TR::pack2(r1, 0.f);
+  const float r2 = r1 - TR::lo(p1);
+  const uint32_t p2 = TR::pack2(r2, 0.f);
+  u32x4 c = {(p0 & 0xffffu) | (p1 << 16), p2 & 0xffffu, 0u, 0u};
+  return c;
+  }
+}
+
+template <typename T, int D, int BMQ, bool MASKED>
+FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const char* auxs, int aux_lane, const FragAddr<T, D>& fa,
+                            const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
+                            const u32x4& ones_s, const u32x4& ones_d,
+                            f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
+                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts) {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  typedef Traits<T> TR;
+  constexpr int NB = BMQ / 32;
+  DkvPipe<T, D, BMQ> pp_;
+  pp_.request(qt, dot, auxs, aux_lane, fa, 0);
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
+    FCSA_FENCE();
+    if (ib == 1) FCSA_STAMP(ts, 2);
+    // ---- M1: S = lc (x) 1 + Q K^T, dP = -delta (x) 1 + dO V^T
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s = TR::mfma32(pp_.aux, ones_s, zero);
+    f32x16 dp = TR::mfma32(pp_.aux, ones_d, zero);
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.qa[kk], kf[kk], s);
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(pp_.da[kk], vf[kk], dp);
+    // ---- T: transposed fragments of this block (dO^T for dV, Q^T for dK)
+    u32x4 td[G::DB][2], tq[G::DB][2];
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      td[db][0] = fa.tr_frag(dot, 32 * ib, db);
+      td[db][1] = fa.tr_frag(dot, 32 * ib + 16, db);
+    }
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      tq[db][0] = fa.tr_frag(qt, 32 * ib, db);
+      tq[db][1] = fa.tr_frag(qt, 32 * ib + 16, db);
+    }
+    FCSA_FENCE();
+    if (ib == 1) FCSA_STAMP(ts, 3);
+    // ---- X: P = exp2(s), dS = P * (dP - delta), packed in place
+    f32x16 pr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pe = fast_exp2(s[r]);
+      if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
+      pr[r] = pe;
+      s[r] = pe * dp[r];
+    }
+    SecondB<T> pb, db_;
+    pb.prep(pr);
+    db_.prep(s);
+    FCSA_FENCE();
+    if (ib == 1) FCSA_STAMP(ts, 4);
+    // ---- R: next block's row fragments (their registers are dead now)
+    if (ib + 1 < NB) pp_.request(qt, dot, auxs, aux_lane, fa, ib + 1);
+    // ---- M2: dV^T += dO^T P, dK^T += Q^T dS
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      dv[db] = TR::mfma32(td[db][0], pb.v[0], dv[db]);
+      dv[db] = TR::mfma32(td[db][1], pb.v[1], dv[db]);
+    }
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      dk[db] = TR::mfma32(tq[db][0], db_.v[0], dk[db]);
+      dk[db] = TR::mfma32(tq[db][1], db_.v[1], dk[db]);
+    }
+    if (ib + 1 < NB) {      // spread the R requests behind the first M2 MFMAs (hipcc otherwise sinks them below the products)
+      constexpr int NM2 = 4 * G::DB, NR = 1 + 2 * G::KS;
+#pragma unroll
+      for (int m = 0; m < NM2; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM2 - 1) / NM2, 0);              // its share of the LDS reads
+      }
+    }
+    if (ib == 1) { FCSA_FENCE(); FCSA_STAMP(ts, 5); }
+  }
+}
+
 template <typename T, int D, int NW, int BMQ, bool BIAS>
 __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYTES ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BMQ * G::ROWB;
-  constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 4;                // Q tile | dO tile | lc[BMQ] | delta[BMQ]
+  // Q tile | dO tile | per-query terms: lc[BMQ] | -delta[BMQ] floats, or (pipelined form) two arrays of 16-byte chunks
+  constexpr bool PIPE = FCSA_DKV_PIPE && Traits<T>::ES == 2 && !BIAS;
+  constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 16;          // (the float form uses the first 2 * BMQ * 4 bytes of the last part)
   static_assert(BMQ % 32 == 0 && BMQ <= NT, "query tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF_B]
 
@@ -410,6 +538,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
   const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
+  // B operands of the aux k-step (dkv_tile_pipe): ones in k-slots 0..2 of the hi = 0 half (S) / of the hi = 1 half (dP)
+  const u32x4 ones3 = {TR::kOne2, TR::kOne2 & 0xffffu, 0u, 0u}, none = {0u, 0u, 0u, 0u};
+  const u32x4 ones_s = fa.hi == 0 ? ones3 : none, ones_d = fa.hi == 1 ? ones3 : none;
+  const int aux_lane = fa.hi * BMQ * 16 + (lane & 31) * 16;
 
   f32x16 dk[G::DB], dv[G::DB];
 #pragma unroll
@@ -445,9 +577,14 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     sq.store(buf, tid);
     sdo.store(buf + TILE_B, tid);
     if (tid < BMQ) {
-      // rows beyond N: lc = -inf makes P exactly 0 there
-      reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -INFINITY;
-      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? -dl_r : 0.f;      // -delta
+      if constexpr (PIPE) {      // rows beyond N: a large negative (finite in f16) normaliser makes P exactly 0 there
+        reinterpret_cast<u32x4*>(buf + 2 * TILE_B)[tid] = split3<T>(row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -30000.f);
+        reinterpret_cast<u32x4*>(buf + 2 * TILE_B + BMQ * 16)[tid] = split3<T>(row_ok ? -dl_r : 0.f);
+      } else {
+        // rows beyond N: lc = -inf makes P exactly 0 there
+        reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -INFINITY;
+        reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? -dl_r : 0.f;      // -delta
+      }
     }
   };
 
@@ -483,7 +620,12 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       FCSA_STAMP(ts, 1);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
-      if constexpr (MASKED) {
+      if constexpr (PIPE) {
+        bool skip = false;
+        if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
+        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, cur + 2 * TILE_B, aux_lane, fa, kf, vf, ones_s, ones_d, dk, dv,
+                                                    kmask, ncm, j, i0, diff, ts);
+      } else if constexpr (MASKED) {
         const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
         if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
       } else {
@@ -516,7 +658,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   }
   }   // pass
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_dkv + 32 * wave, trace_now() - trace_t0);
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (wave & 2) == 0) ts.dump(g_trace_dkv + 32 * ((wave & 1) + 2 * (wave >> 2)), trace_now() - trace_t0);   // waves 0, 1, 4, 5
 #endif
 }
 
@@ -576,7 +718,7 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
-  const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);
+  const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 16);      // 2 x [Q tile | dO tile | per-query terms]
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
   static bool attr_set = false;
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
@@ -599,6 +741,9 @@ template <typename T, int D> static hipError_t launch_dkv_t(const BwdParams& p, 
   return p.bias != nullptr ? launch_dkv_b<T, D, true>(p, s) : launch_dkv_b<T, D, false>(p, s);
 }
 
+#ifdef FCSA_DEV_ONLY      // development builds: one instantiation (bf16, D = 64) for quick compiles / ISA inspection
+#define FCSA_DISPATCH_D(FN, T) if (D == 64) return FN<BF16, 64>(p, s); return hipErrorInvalidValue;
+#else
 #define FCSA_DISPATCH_D(FN, T)                      \
   switch (D) {                                      \
     case 16:  return FN<T, 16>(p, s);               \
@@ -608,6 +753,7 @@ template <typename T, int D> static hipError_t launch_dkv_t(const BwdParams& p, 
     case 128: return FN<T, 128>(p, s);              \
     default:  return hipErrorInvalidValue;          \
   }
+#endif
 
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s) {
   if (p.B * p.H == 0 || p.N == 0) return hipSuccess;

@@ -94,6 +94,7 @@ template <> struct Traits<F16> {
 template <> struct Traits<F32> {
   typedef float elem;
   static constexpr int ES = 4;
+  static constexpr uint32_t kOne2 = 0x3f800000u;     // (unused: the packed-ones tricks are 16-bit only)
   // 4 x v_mfma_f32_32x32x2_f32 over the 4 floats of a 16-byte fragment
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 #pragma unroll

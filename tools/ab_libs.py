@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of several builds of libfcsa_hip.so in ONE process (guide rule 24): per-kernel HIP-event times of the
+C3 step (or --shape B,H,N,D,causal).  usage: ab_libs.py [--rounds R] [--shape ...] tag1 tag2 ...   ('main' = libfcsa_hip.so)"""
+import os, sys, argparse, statistics, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flash_cosine_sim_attention_amd as F
+from flash_cosine_sim_attention_amd import _lib
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--shape", default="4,8,4096,64,1")
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("tags", nargs="+")
+a = ap.parse_args()
+B, H, N, D, causal = (int(x) for x in a.shape.split(","))
+dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+q, k, v = (torch.randn(B, H, N, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(3))
+do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
+def step():
+    q.grad = k.grad = v.grad = None
+    F.flash_cosine_sim_attention(q, k, v, causal=bool(causal)).backward(do)
+libs = {}
+pkg = os.path.join(ROOT, "flash_cosine_sim_attention_amd")
+for t in a.tags:
+    _lib._lib = None
+    _lib.LIB_PATH = os.path.join(pkg, "libfcsa_hip.so" if t == "main" else f"libfcsa_hip_{t}.so")
+    libs[t] = _lib.load()
+res = {t: {} for t in a.tags}
+for r in range(a.rounds + 1):
+    for t in a.tags:
+        _lib._lib = libs[t]
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for _ in range(a.steps): step()
+        torch.cuda.synchronize()
+        st = _lib.profile_collect()
+        _lib.profile_enable(False)
+        if r == 0: continue          # first round = warm-up
+        for s in st: res[t].setdefault(s["name"], []).append(s["total_ms"] / s["calls"] * 1e3)
+names = ["fwd", "bwd_dq", "bwd_dkv", "l2norm"]
+print(f"shape {a.shape} {a.dtype}; median (min) us over {a.rounds} interleaved rounds")
+for t in a.tags:
+    print(f"{t:12s} " + "  ".join(f"{n} {statistics.median(res[t][n]):7.1f} ({min(res[t][n]):7.1f})" for n in names if n in res[t]))

@@ -19,9 +19,10 @@ buf = (C.c_ulonglong * 128)()
 fn = getattr(lib, "fcsa_trace_read_" + which)
 fn.argtypes = [C.POINTER(C.c_ulonglong)]
 assert fn(buf) == 0
-names = {"fwd": ["P1 S0(t) | E1b(t-1) | V0 req, stage store", "P2 PV1(t-1) | E0a | stage loads", "P3 S1(t) | E0b | V1 req", "barrier", "P4 PV0(t) | E1a | K req"], "dkv": ["issue loads (tile t+1)", "ib0: S + dP chains (8 MFMA, frags JIT)", "ib0: exp / dS / pack", "ib0: dV + dK (8 MFMA, tr frags JIT)", "ib1: S + dP", "ib1: exp / dS / pack", "ib1: dV + dK", "-", "stage store", "barrier"], "dq": ["mask word + issue loads (tile t+1)", "tile compute (S, dP, exp, dQ)", "stage store", "barrier"]}.get(which, [f"seg{i}" for i in range(7)])
+names = {"fwd": ["P1 S0(t) | E1b(t-1) | V0 req, stage store", "P2 PV1(t-1) | E0a | stage loads", "P3 S1(t) | E0b | V1 req", "barrier", "P4 PV0(t) | E1a | K req"], "dkv": ["issue loads (tile t+1)", "block 0 (incl. exposed first requests)", "ib1 M1: S + dP chains + T requests", "ib1 X: exp / dS / pack", "ib1 M2: dV + dK + R requests", "blocks 2, 3", "-", "-", "stage store", "barrier"], "dq": ["mask word + issue loads (tile t+1)", "tile compute (S, dP, exp, dQ)", "stage store", "barrier"]}.get(which, [f"seg{i}" for i in range(7)])
 for w in range(4):
     a = list(buf[32 * w:32 * w + 32])
+    if which == "dkv": print("(slot", w, "= wave", (w & 1) + 4 * (w >> 1), ")")
     it, total = a[12], a[13]
     if it == 0: print("wave", w, "no iterations"); continue
     seg = a[:len(names)]
