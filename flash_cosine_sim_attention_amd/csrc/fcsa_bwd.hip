@@ -37,6 +37,9 @@
 #ifndef FCSA_DQ_2W_BYTES
 #define FCSA_DQ_2W_BYTES 128
 #endif
+#ifndef FCSA_DKV_DMA
+#define FCSA_DKV_DMA 1         // Q / dO tiles of the pipelined dKV form by LDS-DMA (0: through registers, for A/B builds)
+#endif
 #ifndef FCSA_DKV_PIPE
 #define FCSA_DKV_PIPE 1        // software-pipelined dKV tile (16-bit types, no bias); 0 = the plain form, for A/B builds
 #endif
@@ -557,15 +560,30 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   if constexpr (BIAS)
     bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
 
+  // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
+  constexpr bool DMA = PIPE && FCSA_DKV_DMA && (BMQ * G::ROWB) % 1024 == 0;
   Stager<T, D, BMQ, NT> sq, sdo;
-  sq.init(p.q.sn, tid);
-  sdo.init(p.d_out.sn, tid);
+  DmaStager<T, D, DMA ? BMQ : 1024, NW> dq_, ddo_;
+  if constexpr (DMA) {
+    dq_.init(p.q.sn, wave, lane);
+    ddo_.init(p.d_out.sn, wave, lane);
+  } else {
+    sq.init(p.q.sn, tid);
+    sdo.init(p.d_out.sn, tid);
+  }
   float lc_r = 0.f, dl_r = 0.f;
   bool row_ok = false;
-  auto load_tile = [&](int t) {
+  // loads of tile t; `buf` = the LDS buffer it is going to (the DMA form writes it right away: the caller guarantees that no
+  // wave still reads that buffer)
+  auto load_tile = [&](int t, char* buf) {
     const int i0 = t * BMQ;
-    sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0);
-    sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
+    if constexpr (DMA) {
+      dq_.issue(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0, buf, wave);
+      ddo_.issue(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0, buf + TILE_B, wave);
+    } else {
+      sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0);
+      sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
+    }
     if (tid < BMQ) {       // raw loads only: any arithmetic on them here would force an immediate vmcnt wait
       const int i = min(i0 + tid, p.N - 1);
       lc_r = invl_row[i];
@@ -574,8 +592,12 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     }
   };
   auto store_tile = [&](char* buf) {
-    sq.store(buf, tid);
-    sdo.store(buf + TILE_B, tid);
+    if constexpr (DMA) {
+      dma_wait();
+    } else {
+      sq.store(buf, tid);
+      sdo.store(buf + TILE_B, tid);
+    }
     if (tid < BMQ) {
       if constexpr (PIPE) {      // rows beyond N: a large negative (finite in f16) normaliser makes P exactly 0 there
         reinterpret_cast<u32x4*>(buf + 2 * TILE_B)[tid] = split3<T>(row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -30000.f);
@@ -589,7 +611,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   };
 
   if (t0 < QT) {
-    load_tile(t0);
+    load_tile(t0, smem);
     store_tile(smem);
   }
   __syncthreads();
@@ -616,7 +638,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       char* nxt = smem + (par ^ 1) * BUF_B;
       const bool more = t + 1 < QT;
       FCSA_STAMP(ts, 0);
-      if (more) load_tile(t + 1);
+      if (more) load_tile(t + 1, nxt);
       FCSA_STAMP(ts, 1);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
@@ -642,19 +664,26 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   run(std::true_type{}, t0, t_m);
   run(std::false_type{}, t_m, QT);
 
-  if (j < p.M) {
-    char* dkrow = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)j * p.dk.sn;
-    char* dvrow = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)j * p.dv.sn;
-    // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
-    const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
-    if (p.rk != nullptr) {      // dk = l2norm_backward(dKh): p.k holds k^ (K/V with heads only)
-      const char* xrow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
-      store_row_tile_l2norm_bwd<T, D>(dkrow, dk, kmul, fa.hi, xrow, 1.f,
-                                      p.rk + (((int64_t)b * p.H + h) * p.M + j) * p.G, p.lgm, p.norm_eps);
-    } else {
-      store_row_tile<T, D>(dkrow, dk, kmul, fa.hi, p.dk_f32 != 0);
+  // Epilogue through the LDS (RowEpilogue): every tile ended with a barrier, so no wave still reads the staging buffers.
+  {
+    typedef RowEpilogue<T, D> EP;
+    char* scr = smem + wave * EP::BYTES;
+    const int rows_valid = p.M - nw;
+    if (rows_valid > 0) {
+      // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
+      const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
+      char* dk0 = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)nw * p.dk.sn;
+      char* dv0 = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)nw * p.dv.sn;
+      if (p.rk != nullptr) {      // dk = l2norm_backward(dKh): p.k holds k^ (K/V with heads only)
+        const char* x0 = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)nw * p.k.sn;
+        EP::store(scr, dk, kmul, lane, dk0, p.dk.sn, rows_valid, false, x0, p.k.sn, 1.f,
+                  p.rk + (((int64_t)b * p.H + h) * p.M + nw) * p.G, p.G, p.lgm, p.norm_eps);
+      } else {
+        EP::store(scr, dk, kmul, lane, dk0, p.dk.sn, rows_valid, p.dk_f32 != 0, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
+      }
+      EP::store(scr, dv, 1.f, lane, dv0, p.dv.sn, rows_valid, p.dv_f32 != 0, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     }
-    store_row_tile<T, D>(dvrow, dv, 1.f, fa.hi, p.dv_f32 != 0);
+    if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
   }
   }   // pass
 #ifdef FCSA_TRACE
@@ -718,7 +747,8 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
-  const size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 16);      // 2 x [Q tile | dO tile | per-query terms]
+  size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 16);      // 2 x [Q tile | dO tile | per-query terms]
+  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
   static bool attr_set = false;
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;

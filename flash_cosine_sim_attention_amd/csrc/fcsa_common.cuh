@@ -310,6 +310,60 @@ template <typename T, int D, int ROWS, int NT> struct Stager {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// global -> LDS staging WITHOUT registers: buffer_load_dwordx4 ... lds (LDS-DMA).  A wave instruction moves 64 x 16 bytes to
+// 1 KiB of CONSECUTIVE LDS bytes (address = M0 base + lane * 16: no per-lane scatter), so the XOR swizzle of TileGeom moves
+// to the SOURCE side: the lane that fills physical chunk c' of row r fetches logical chunk c' ^ swz(r) of that row (same
+// 128/256-byte row, so the coalescing of the global read is unchanged).  Rows past the end of the tensor slice read as zero
+// through the descriptor's range check, like the register path.  A piece is 1 KiB = 1024 / ROWB tile rows; wave w of NW owns
+// pieces w, w + NW, ...  Completion is tracked by vmcnt; hipcc's __syncthreads() waits for it (vmcnt(0)) by itself.
+// Compared with Stager: no staging registers (PER * 4 per tensor), no ds_write_b128 passes.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int ROWS, int NW> struct DmaStager {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  static constexpr int NPIECE = ROWS * G::ROWB / 1024;                  // 1 KiB pieces per tile
+  static_assert(ROWS * G::ROWB % 1024 == 0, "tile must be a whole number of 1 KiB pieces");
+  static constexpr int PER = (NPIECE + NW - 1) / NW;                    // pieces per wave
+  static constexpr int ROW_BYTES = D * Traits<T>::ES;
+  int voff[PER];         // loop-invariant source byte offset of this lane inside a tile, per piece
+
+  FCSA_DEV void init(int64_t pitch, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int lds_off = (wave + i * NW) * 1024 + lane * 16;           // byte offset inside the LDS tile
+      const int row = lds_off / G::ROWB, cp = (lds_off % G::ROWB) >> 4;
+      const int c = cp ^ G::swz(row);
+      // padding chunks of a row (D = 96: 12 of 16) are never read: point them at chunk 0 (valid, already fetched)
+      voff[i] = (int)(row * pitch + (c < G::CPR ? c : 0) * 16);
+    }
+  }
+  // g: address of (row 0, feature 0) of the tile (wave-uniform); rows >= rows_valid are zero-filled.
+  // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write that may alias any later
+  // ds_read of the same __shared__ array and drains it (s_waitcnt vmcnt(0)) in front of the next tile's first fragment read,
+  // i.e. right after issuing it.  Hidden from the compiler, the transfer overlaps the whole tile; the caller waits for it with
+  // dma_wait() before the barrier that publishes the buffer.  M0 (LDS base of the DMA) is saved and restored around the statement.
+  FCSA_DEV void issue(const char* g, int64_t pitch, int rows_valid, char* tile, int wave) const {
+    int64_t bytes = rows_valid > 0 ? (int64_t)(rows_valid - 1) * pitch + ROW_BYTES : 0;
+    if (bytes > 0x7fffffff) bytes = 0x7fffffff;
+    const uint64_t ga = reinterpret_cast<uint64_t>(g);
+    u32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((uint32_t)ga);
+    rs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32) & 0xffffu);      // base[47:32], stride 0
+    rs[2] = __builtin_amdgcn_readfirstlane((uint32_t)bytes);                       // num_records
+    rs[3] = 0x00020000u;                                                           // raw buffer, 32-bit data format
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile);   // LDS byte address (low 32 bits of the flat shared address)
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (NPIECE % NW == 0 || wave + i * NW < NPIECE) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds0 + (uint32_t)(wave + i * NW) * 1024u), "v"(voff[i]), "s"(rs) : "memory");
+      }
+  }
+};
+// all LDS-DMA transfers of this wave have landed (vmcnt also counts the compiler's own loads and stores: conservative)
+FCSA_DEV void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Store the C-layout accumulators of a [32 own positions x D] tile: lane (row, hi) holds features
 // 32*db + 8*rq + 4*hi + 0..3.  Output element type: float (as_f32 or T = F32) or the 16-bit T.
 template <typename T, int D>
@@ -404,6 +458,103 @@ FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileG
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row epilogue through LDS.  The C layout gives a lane 4 consecutive features of ITS row per (db, rq): stored directly that is
+// 8 (or 16) row-strided 8-byte stores per lane and tensor -- every wave instruction touches 64 different rows, and the stores
+// queue up behind each other at the end of the kernel when every wave of every CU is in its epilogue at once.  Measured on the
+// dKV kernel (C3): 19 of 143 us were the epilogue (12.5 us the plain stores, 6.4 us the fused l2norm backward with its two
+// 8-byte-per-lane reads of the normalised row).  Here the wave transposes its [32 rows x D] f32 tile through a private LDS
+// scratch and then works in "row chunk" form: a lane owns 8 consecutive features (one 16-byte chunk of the 16-bit output) of
+// a row, LPR consecutive lanes own a row, so every global access of a wave covers whole rows / whole 16-byte chunks:
+//     16-bit D = 64: a wave instruction writes 8 complete 128-byte rows (1 KiB contiguous when the rows are).
+// The l2norm backward  dx = r (g - x^ <g, x^>_group)  needs the group dot product across the 2^lgm lanes that hold a group:
+// lgm DPP butterfly steps.  The caller guarantees that no other wave still uses `scr` (a barrier after the last tile) and
+// synchronises again before the scratch region is overwritten by staging.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D> struct RowEpilogue {
+  typedef Traits<T> TR;
+  typedef TileGeom<D, TR::ES> G;
+  static constexpr int CH = D / 8;                                                 // 8-feature chunks per row
+  static constexpr int LPR = CH <= 2 ? 2 : CH <= 4 ? 4 : CH <= 8 ? 8 : 16;         // lanes per row (power of two >= CH)
+  static constexpr int RPP = 64 / LPR;                                             // rows per pass
+  static constexpr int NP = 32 / RPP;                                              // passes over the 32 rows
+  static constexpr int PITCH = D * 4 + 16;                                         // scratch row pitch: +16 keeps the b128 writes conflict free
+  static constexpr int BYTES = 32 * PITCH;                                         // scratch per wave
+
+  // sum over the aligned block of (1 << steps) lanes this lane belongs to (steps <= 4)
+  static FCSA_DEV float lane_block_sum(float v, int steps) {
+    if (steps >= 1) v += as_f32(__builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    if (steps >= 2) v += as_f32(__builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    if (steps >= 3) v += as_f32(__builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror (quads are uniform)
+    if (steps >= 4) v += as_f32(__builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror (halves are uniform)
+    return v;
+  }
+
+  // acc (C layout, lane = row (lane & 31), hi = lane >> 5) * mul  ->  out rows.  rows_valid: rows >= rows_valid are not stored.
+  // xn0 != nullptr: fused l2norm backward against the normalised rows xn0 + row * xn_pitch (element type T, scaled by xn_scale)
+  // with inverse norms inv_norm0[row * NG + group]; groups are (8 << lgm) features wide.
+  static FCSA_DEV void store(char* scr, const f32x16 (&acc)[G::DB], float mul, int lane, char* out0, int64_t out_pitch, int rows_valid,
+                             bool out_f32, const char* xn0, int64_t xn_pitch, float xn_scale, const float* inv_norm0, int NG, int lgm,
+                             float eps) {
+    const int x = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        if (32 * db + 8 * rq < D) {
+          const f32x4 v = {acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul, acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul};
+          *reinterpret_cast<f32x4*>(scr + x * PITCH + (32 * db + 8 * rq + 4 * hi) * 4) = v;
+        }
+    // (LDS operations of one wave execute in order: the reads below see the writes above)
+    const int c = lane % LPR, rr = lane / LPR;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      const int row = pp * RPP + rr;
+      const bool live = (CH == LPR || c < CH) && row < rows_valid;
+      const int cc = (CH == LPR || c < CH) ? c : 0;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(scr + row * PITCH + cc * 32);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(scr + row * PITCH + cc * 32 + 16);
+      float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      if (xn0 != nullptr) {
+        float xh[8];
+        const int rowc = row < rows_valid ? row : 0;            // clamped: always a valid address (rows_valid >= 1 here)
+        const char* xr = xn0 + (int64_t)rowc * xn_pitch + cc * 8 * TR::ES;
+        if constexpr (TR::ES == 4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xr), b2 = *reinterpret_cast<const f32x4*>(xr + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xh[e] = a[e] * xn_scale; xh[4 + e] = b2[e] * xn_scale; }
+        } else {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(xr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xh[2 * e] = TR::lo(a[e]) * xn_scale; xh[2 * e + 1] = TR::hi(a[e]) * xn_scale; }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot += g[e] * xh[e];
+        if (!(CH == LPR || c < CH)) dot = 0.f;                  // padding lanes of a row (D = 96) contribute nothing
+        dot = lane_block_sum(dot, lgm);
+        const float r = inv_norm0[(int64_t)rowc * NG + (cc >> lgm)];
+        const bool clamped = r >= 1.f / eps;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = clamped ? g[e] * r : r * (g[e] - xh[e] * dot);
+      }
+      if (live) {
+        if (TR::ES == 4 || out_f32) {
+          char* o = out0 + (int64_t)row * out_pitch + c * 32;
+          const f32x4 a = {g[0], g[1], g[2], g[3]}, b2 = {g[4], g[5], g[6], g[7]};
+          *reinterpret_cast<f32x4*>(o) = a;
+          *reinterpret_cast<f32x4*>(o + 16) = b2;
+        } else if constexpr (TR::ES == 2) {
+          u32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = TR::pack2(g[2 * e], g[2 * e + 1]);
+          *reinterpret_cast<u32x4*>(out0 + (int64_t)row * out_pitch + c * 16) = u;
+        }
+      }
+    }
+  }
+};
 
 // ---- in-kernel phase timing (trace builds only: make EXTRA=-DFCSA_TRACE OUT=../libfcsa_hip_trace.so) ----
 // s_memtime stamps are ISSUED at phase boundaries and only READ after an explicit lgkmcnt(0) at the end of
