@@ -37,6 +37,9 @@
 #ifndef FCSA_DQ_2W_BYTES
 #define FCSA_DQ_2W_BYTES 128
 #endif
+#ifndef FCSA_DQ_DMA
+#define FCSA_DQ_DMA 1          // K / V stages of the dQ kernel by LDS-DMA (16-bit types)
+#endif
 #ifndef FCSA_DKV_DMA
 #define FCSA_DKV_DMA 1         // Q / dO tiles of the pipelined dKV form by LDS-DMA (0: through registers, for A/B builds)
 #endif
@@ -206,17 +209,34 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 
   // stages u = t / SUB of SUB 64-key tiles: loads of stage u+1 are issued at the first tile of stage u, stored after its last
   // tile, one barrier per stage (double-buffered LDS)
+  // K / V stages: LDS-DMA for 16-bit types (no staging registers, no ds_write passes; see DmaStager), else through registers
+  constexpr bool DMA = FCSA_DQ_DMA && TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
   Stager<T, D, BNS, NT> sk, sv;
-  sk.init(p.k.sn, tid);
-  sv.init(p.v.sn, tid);
+  DmaStager<T, D, DMA ? BNS : 1024, NW> dk_, dv_;
+  if constexpr (DMA) {
+    dk_.init(p.k.sn, wave, lane);
+    dv_.init(p.v.sn, wave, lane);
+  } else {
+    sk.init(p.k.sn, tid);
+    sv.init(p.v.sn, tid);
+  }
   uint8_t mb = 1;
   const int nst = (nt + SUB - 1) / SUB;
   if (nt > 0) {
-    sk.load(kbase, p.k.sn, p.M);
-    sv.load(vbase, p.v.sn, p.M);
+    if constexpr (DMA) {
+      dk_.issue(kbase, p.k.sn, p.M, smem, wave);
+      dv_.issue(vbase, p.v.sn, p.M, smem + HALF_B, wave);
+    } else {
+      sk.load(kbase, p.k.sn, p.M);
+      sv.load(vbase, p.v.sn, p.M);
+    }
     if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
-    sk.store(smem, tid);
-    sv.store(smem + HALF_B, tid);
+    if constexpr (DMA) {
+      dma_wait();
+    } else {
+      sk.store(smem, tid);
+      sv.store(smem + HALF_B, tid);
+    }
   }
   __syncthreads();
   // Every prologue load (Q / dO / K / V fragments, first stage) is complete on the real path; say so on ALL paths.
@@ -251,9 +271,14 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
           mb = key < p.M ? mrow[key] : (uint8_t)0;
         }
       }
-      if (sub == 0 && more) {
-        sk.load(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, p.M - (u + 1) * BNS);
-        sv.load(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, p.M - (u + 1) * BNS);
+      if (sub == 0 && more) {       // the buffer of stage u + 1 was last read in stage u - 1, which ended with a barrier
+        if constexpr (DMA) {
+          dk_.issue(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, p.M - (u + 1) * BNS, snxt, wave);
+          dv_.issue(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, p.M - (u + 1) * BNS, snxt + HALF_B, wave);
+        } else {
+          sk.load(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, p.M - (u + 1) * BNS);
+          sv.load(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, p.M - (u + 1) * BNS);
+        }
       }
       FCSA_STAMP(ts, 1);
       if constexpr (MASKED) {
@@ -265,8 +290,12 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       FCSA_STAMP(ts, 2);
       if (last_of_stage) {                                 // workgroup-uniform
         if (more) {
-          sk.store(snxt, tid);
-          sv.store(snxt + HALF_B, tid);
+          if constexpr (DMA) {
+            dma_wait();
+          } else {
+            sk.store(snxt, tid);
+            sv.store(snxt + HALF_B, tid);
+          }
         }
         FCSA_STAMP(ts, 3);
         __syncthreads();
@@ -278,15 +307,22 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   run(std::false_type{}, 0, t_split);
   run(std::true_type{}, t_split, nt);
 
-  if (i < p.N) {
-    char* row = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)i * p.dq.sn;
-    if (p.rq != nullptr) {      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
-      const char* xrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
-      store_row_tile_l2norm_bwd<T, D>(row, dq, p.scale, fa.hi, xrow, p.q_scaled ? 1.f / p.c1 : 1.f,
-                                      p.rq + (((int64_t)b * p.H + h) * p.N + i) * p.G, p.lgm, p.norm_eps);
-    } else {
-      store_row_tile<T, D>(row, dq, p.scale, fa.hi, p.dq_f32 != 0);     // cu:1580-1582: dS *= scale
+  // Epilogue through the LDS (RowEpilogue): every stage ended with a barrier, so no wave still reads the staging buffers.
+  {
+    typedef RowEpilogue<T, D> EP;
+    char* scr = smem + wave * EP::BYTES;
+    const int rows_valid = p.N - mw;
+    if (rows_valid > 0) {
+      char* dq0 = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)mw * p.dq.sn;
+      if (p.rq != nullptr) {      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
+        const char* x0 = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)mw * p.q.sn;
+        EP::store(scr, dq, p.scale, lane, dq0, p.dq.sn, rows_valid, false, x0, p.q.sn, p.q_scaled ? 1.f / p.c1 : 1.f,
+                  p.rq + (((int64_t)b * p.H + h) * p.N + mw) * p.G, p.G, p.lgm, p.norm_eps);
+      } else {
+        EP::store(scr, dq, p.scale, lane, dq0, p.dq.sn, rows_valid, p.dq_f32 != 0, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);     // cu:1580-1582: dS *= scale
+      }
     }
+    if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
   }
   }   // pass
 #ifdef FCSA_TRACE
@@ -723,7 +759,8 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   constexpr int SUB = NW == 8 ? 2 : 1;
-  const size_t lds = 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K stage + V stage)
+  size_t lds = 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K stage + V stage)
+  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
   static bool attr_set = false;
   if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;

@@ -37,6 +37,10 @@
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
 
+#ifndef FCSA_FWD_DMA
+#define FCSA_FWD_DMA 1         // K / V tiles of the 32-rows-per-wave forward kernel by LDS-DMA (16-bit types)
+#endif
+
 namespace fcsa {
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
@@ -371,9 +375,19 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   //   mid()    : barrier (all LDS reads of tile t returned, tile t+1 visible), K fragment requests of tile t+1
   //   PV products of tile t
   // Buffer (t+1)&1 held tile t-1, whose last reads every wave completed before the barrier of t-1.
+  // DMA form (16-bit types): tile t+1 goes global -> LDS by LDS-DMA (DmaStager: no staging registers, no ds_write passes), issued
+  // at the top of tile t into the buffer whose last reads finished before the barrier of tile t-1, and waited for right before
+  // the barrier of tile t.
+  constexpr bool DMA = FCSA_FWD_DMA && TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
   Stager<T, D, BN, NT> sk, sv;
-  sk.init(p.k.sn, tid);
-  sv.init(p.v.sn, tid);
+  DmaStager<T, D, DMA ? BN : 1024, NW> dk_, dv_;
+  if constexpr (DMA) {
+    dk_.init(p.k.sn, wave, lane);
+    dv_.init(p.v.sn, wave, lane);
+  } else {
+    sk.init(p.k.sn, tid);
+    sv.init(p.v.sn, tid);
+  }
   uint8_t mb = 1;
   u32x4 kf[2][G::KS];
   auto request_k = [&](const char* kt) {
@@ -383,8 +397,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(kt, 32 * jb, kk);
   };
   if (nt > 0) {
-    sk.load(kbase, p.k.sn, Mk);
-    sv.load(vbase, p.v.sn, Mk);
+    if constexpr (DMA) {
+      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
+      dv_.issue(vbase, p.v.sn, Mk, smem + TILE_B, wave);
+    } else {
+      sk.load(kbase, p.k.sn, Mk);
+      sv.load(vbase, p.v.sn, Mk);
+    }
     if (mrow) mb = lane < Mk ? mrow[lane] : (uint8_t)0;
   }
   // Every prologue load (Q fragments, first tile, mask byte) is complete here on the real path; say so on ALL
@@ -392,7 +411,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   // merge never clears that, and each iteration waits with vmcnt(0) at its first MFMA -- right after issuing
   // the prefetch of tile t+2, which serialises the prefetch with the compute meant to hide it.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
-  if (nt > 0) {
+  if constexpr (DMA) {
+    dma_wait();
+  } else if (nt > 0) {
     sk.store(smem, tid);
     sv.store(smem + TILE_B, tid);
     if (nt > 1) {
@@ -430,18 +451,26 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
           mb = key < Mk ? mrow[key] : (uint8_t)0;
         }
       }
-      if (t + 1 < nt) {
-        sk.store(knxt, tid);
-        sv.store(knxt + TILE_B, tid);
-      }
-      FCSA_STAMP(ts, 1);
-      if (t + 2 < nt) {
-        sk.load(kbase + (int64_t)(j0 + 2 * BN) * p.k.sn, p.k.sn, Mk - (j0 + 2 * BN));
-        sv.load(vbase + (int64_t)(j0 + 2 * BN) * p.v.sn, p.v.sn, Mk - (j0 + 2 * BN));
+      if constexpr (DMA) {
+        if (t + 1 < nt) {
+          dk_.issue(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN), knxt, wave);
+          dv_.issue(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, Mk - (j0 + BN), knxt + TILE_B, wave);
+        }
+      } else {
+        if (t + 1 < nt) {
+          sk.store(knxt, tid);
+          sv.store(knxt + TILE_B, tid);
+        }
+        FCSA_STAMP(ts, 1);
+        if (t + 2 < nt) {
+          sk.load(kbase + (int64_t)(j0 + 2 * BN) * p.k.sn, p.k.sn, Mk - (j0 + 2 * BN));
+          sv.load(vbase + (int64_t)(j0 + 2 * BN) * p.v.sn, p.v.sn, Mk - (j0 + 2 * BN));
+        }
       }
       FCSA_STAMP(ts, 2);
       auto mid = [&]() {
         FCSA_STAMP(ts, 5);
+        if constexpr (DMA) dma_wait();
         __syncthreads();
         FCSA_STAMP(ts, 6);
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
@@ -472,11 +501,16 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     continue;
   }
   const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift
-  if (i < p.N) {
-    // saved for the backward in the GLOBAL shift convention (DYN: shift 0, i.e. 1 / sum_j exp(S_ij))
-    if (p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = DYN ? inv * __builtin_amdgcn_exp2f(-c2row) : inv;
-    char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
-    store_row_tile<T, D>(orow, o, inv, fa.hi, false);
+  // saved for the backward in the GLOBAL shift convention (DYN: shift 0, i.e. 1 / sum_j exp(S_ij))
+  if (i < p.N && p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = DYN ? inv * __builtin_amdgcn_exp2f(-c2row) : inv;
+  // O rows through the LDS (RowEpilogue): every wave issued its last LDS read of the key loop before the final barrier, so the
+  // staging buffers are free; the next pass's prologue must not overwrite the scratch while another wave still reads it.
+  {
+    typedef RowEpilogue<T, D> EP;
+    if (p.N - mw > 0)
+      EP::store(smem + wave * EP::BYTES, o, inv, lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
+                p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
+    if (pass + 1 < npass) __syncthreads();
   }
   }   // pass
 #ifdef FCSA_TRACE
@@ -872,7 +906,8 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  const size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K tile + V tile) of 64 keys
+  size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K tile + V tile) of 64 keys
+  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = fwd_kernel<T, D, NW, BIAS, DYN>;
   static bool attr_set = false;                  // per instantiation; the attribute is sticky
   if (!attr_set) {
@@ -909,6 +944,10 @@ static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
 
 template <typename T>
 static hipError_t launch_fwd_d(int D, const FwdParams& p, hipStream_t s) {
+#ifdef FCSA_DEV_ONLY      // development builds: one instantiation (bf16, D = 64)
+  if constexpr (std::is_same<T, BF16>::value) { if (D == 64) return launch_fwd_t<T, 64>(p, s); }
+  return hipErrorInvalidValue;
+#else
   switch (D) {
     case 16:  return launch_fwd_t<T, 16>(p, s);
     case 32:  return launch_fwd_t<T, 32>(p, s);
@@ -917,6 +956,7 @@ static hipError_t launch_fwd_d(int D, const FwdParams& p, hipStream_t s) {
     case 128: return launch_fwd_t<T, 128>(p, s);
     default:  return hipErrorInvalidValue;
   }
+#endif
 }
 
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s) {
