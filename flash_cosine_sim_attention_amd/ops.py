@@ -7,85 +7,84 @@ Differences from the reference, all inside the boundary:
     instead of two eager F.normalize passes outside the autograd.Function
     (flash_cosine_sim_attention.py:320-321), so `FlashCosineSimAttention.backward` returns
     gradients w.r.t. the RAW q, k;
-  * GPU tensors only run on the hand-written gfx950 kernels; there is no silent fallback.
-    CPU tensors are rejected here (the reference routes them to its forward-only tiled
-    PyTorch loop, flash_cosine_sim_attention.py:130-241; that loop is restated as the
-    test oracle in oracle/, not shipped as a product path).
+  * GPU tensors only ever run on the hand-written gfx950 kernels; there is no silent fallback
+    (a missing libfcsa_hip.so raises ImportError).  CPU tensors take this package's own
+    forward-only blockwise path (`cpu.py`), as they do in the reference (py:322-323).
+
+Limits (documented divergence): with l2norm_qk the logit range is +-scale*groups; the library
+refuses scale*groups > 87 (exp of the range leaves float32) where the reference kernel would
+overflow / zero rows silently.
 """
 from __future__ import annotations
 
-from functools import partial
-
 import torch
-import torch.nn.functional as F
-from torch import einsum
 from torch.autograd import Function
 
 from . import _core
-
-
-def exists(val):
-    return val is not None
+from . import cpu as _cpu
 
 
 # ---------------------------------------------------------------------------------------------
-# l2norm helpers (flash_cosine_sim_attention.py:38-65)
+# l2norm helpers: public exports of the reference package (flash_cosine_sim_attention.py:38-65).
+# Differentiable torch code; the fused operator does not call them.
 # ---------------------------------------------------------------------------------------------
+
+def _norm_floor(t: torch.Tensor) -> float:
+    # the reference clamps the norm at F.normalize's 1e-12 on the GPU and, on the CPU, at 1e-3 for the 16-bit types (py:38-48)
+    return 1e-12 if (t.is_cuda or t.dtype == torch.float32) else 1e-3
+
 
 def l2norm(t):
-    return F.normalize(t, dim=-1)
+    """t / max(||t||_2, eps) over the last dimension."""
+    length = torch.linalg.vector_norm(t, dim=-1, keepdim=True)
+    return t / length.clamp_min(_norm_floor(t))
 
 
 def grouped_l2norm(t, groups=1):
-    shape = t.shape
-    dim = shape[-1]
-    t = t.reshape(*shape[:-1], groups, dim // groups)
-    t = l2norm(t)
-    return t.reshape(shape)
+    """l2norm of each of `groups` equal slices of the last dimension."""
+    width = t.shape[-1]
+    if groups < 1 or width % groups:
+        raise ValueError(f"groups ({groups}) must divide the last dimension ({width})")
+    return l2norm(t.unflatten(-1, (groups, width // groups))).flatten(-2)
 
 
 def l2norm_tensors(*tensors, groups=1):
-    """Differentiable grouped l2norm of each tensor, cast back to the first tensor's dtype
-    (flash_cosine_sim_attention.py:57-65).  Public export of the reference package."""
-    assert len(tensors) > 0
-    dtype = tensors[0].dtype
-    fn = partial(grouped_l2norm, groups=groups)
-    tensors = tuple(map(fn, tensors))
-    tensors = tuple(map(lambda t: t.type(dtype), tensors))
-    return tensors
+    """Grouped l2norm of every tensor, each cast to the dtype of the FIRST one (py:57-65)."""
+    if not tensors:
+        raise ValueError("l2norm_tensors needs at least one tensor")
+    target = tensors[0].dtype
+    return tuple(grouped_l2norm(t, groups).to(target) for t in tensors)
 
 
 # ---------------------------------------------------------------------------------------------
-# plain O(N*M) attention in PyTorch ops (flash_cosine_sim_attention.py:75-126): public export,
-# runs on whatever device the inputs live on.  Not used by the fused op.
+# O(N*M)-memory attention in plain PyTorch ops: the reference's `plain_cosine_sim_attention`
+# (py:75-126), kept as a public export.  Runs wherever its inputs live.  Not used by the fused op.
 # ---------------------------------------------------------------------------------------------
 
 def plain_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
                                l2norm_qk=True, attn_bias_batch_dim=False):
-    assert not (causal and exists(mask)), 'mask should not be supplied if causality is needed'
-    merged = q.ndim == 3
-    single_head_kv = k.ndim == 3
-    if merged:
-        assert k.ndim == 3 and v.ndim == 3, \
-            'if batch and heads are merged for queries, keys and values must also similarly have only 3 dimensions'
-        attn_bias_batch_dim = True
-        q = q[:, None, ...]
-    if l2norm_qk:
-        q, k = l2norm_tensors(q, k, groups=groups)
-    kv_eq = 'b j d' if single_head_kv else 'b h j d'
-    sim = einsum(f'b h i d, {kv_eq} -> b h i j', q, k) * scale
-    if exists(attn_bias):
-        sim = sim + attn_bias.unsqueeze(1 if attn_bias_batch_dim else 0)
-    mask_value = -torch.finfo(sim.dtype).max
-    if causal:
-        i, j = sim.shape[-2:]
-        causal_mask = torch.ones((i, j), device=q.device, dtype=torch.bool).triu(j - i + 1)
-        sim = sim.masked_fill(causal_mask, mask_value)
-    if exists(mask):
-        sim = sim.masked_fill(~mask[:, None, None, :], mask_value)
-    attn = sim.softmax(dim=-1)
-    out = einsum(f'b h i j, {kv_eq} -> b h i d', attn, v)
-    return out.squeeze(1) if merged else out
+    if causal and mask is not None:
+        raise AssertionError("mask should not be supplied if causality is needed")
+    squeeze_heads = q.dim() == 3                       # merged batch-heads queries
+    if squeeze_heads:
+        if k.dim() != 3 or v.dim() != 3:
+            raise AssertionError("if batch and heads are merged for queries, keys and values must also similarly have only 3 dimensions")
+        attn_bias_batch_dim, q = True, q.unsqueeze(1)
+    q, k = l2norm_tensors(q, k, groups=groups) if l2norm_qk else (q, k)
+    keys = k.unsqueeze(1) if k.dim() == 3 else k       # single-headed K/V broadcast over the heads
+    values = v.unsqueeze(1) if v.dim() == 3 else v
+    logits = torch.matmul(q, keys.transpose(-1, -2)) * scale
+    if attn_bias is not None:
+        logits = logits + attn_bias.unsqueeze(1 if attn_bias_batch_dim else 0)
+    lowest = -torch.finfo(logits.dtype).max
+    n, m = logits.shape[-2:]
+    if causal:                                         # key j is visible to query i iff j - (m - n) <= i
+        future = torch.ones((n, m), dtype=torch.bool, device=logits.device).triu(m - n + 1)
+        logits = logits.masked_fill(future, lowest)
+    if mask is not None:
+        logits = logits.masked_fill(~mask[:, None, None, :], lowest)
+    out = torch.matmul(logits.softmax(dim=-1), values)
+    return out.squeeze(1) if squeeze_heads else out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -95,22 +94,27 @@ def plain_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, grou
 class FlashCosineSimAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, attn_bias, scale, groups, causal, l2norm_qk, attn_bias_batch_dim):
-        should_backwards = any(exists(t) and t.requires_grad for t in (q, k, v, attn_bias))     # cu:1689
+        should_backwards = any(t is not None and t.requires_grad for t in (q, k, v, attn_bias))     # cu:1689
         o, saved = _core.attention_forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal,
                                            l2norm_qk=l2norm_qk, groups=groups, need_backward=should_backwards)
         ctx.should_backwards = should_backwards
         if not should_backwards:
             return o
-        ctx.saved = saved
+        # tensors go through save_for_backward (py:270): no reference cycle through ctx, in-place modification of a saved
+        # input is detected, saved-tensor hooks (checkpointing, offload) apply; scalars stay plain attributes
+        ctx.save_for_backward(saved.o, saved.inv_l, saved.q, saved.k, saved.v, saved.mask, saved.attn_bias,
+                              saved.qn, saved.kn, saved.rq, saved.rk)
+        ctx.scalars = (saved.scale, saved.groups, saved.causal, saved.l2norm_qk, saved.attn_bias_batch_dim)
         ctx.shapes = (q.shape, k.shape, v.shape)
-        ctx.bias_grad = exists(attn_bias) and attn_bias.requires_grad
+        ctx.bias_grad = attn_bias is not None and attn_bias.requires_grad
         return o
 
     @staticmethod
     def backward(ctx, do):
         assert ctx.should_backwards
         q_shape, k_shape, v_shape = ctx.shapes
-        dq, dk, dv, db = _core.attention_backward(do, ctx.saved, q_shape, k_shape, v_shape, ctx.bias_grad)
+        saved = _core.Saved(*ctx.saved_tensors, *ctx.scalars)
+        dq, dk, dv, db = _core.attention_backward(do, saved, q_shape, k_shape, v_shape, ctx.bias_grad)
         return dq, dk, dv, None, db, None, None, None, None, None
 
 
@@ -119,10 +123,13 @@ flash_cosine_sim_attention_hip = FlashCosineSimAttention.apply
 
 def flash_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
                                l2norm_qk=True, attn_bias_batch_dim=False):
-    """Fused cosine-similarity attention; signature of flash_cosine_sim_attention.py:308-319."""
-    if not q.is_cuda:
-        raise RuntimeError(
-            'flash_cosine_sim_attention_amd runs on MI355X GPU tensors only (hand-written HIP kernels, '
-            'no CPU fallback); use plain_cosine_sim_attention for CPU tensors')
+    """Fused cosine-similarity attention; signature of flash_cosine_sim_attention.py:308-319.
+
+    GPU tensors: hand-written gfx950 kernels, forward and backward (gradients w.r.t. the raw q, k, v, attn_bias).
+    CPU tensors: forward-only blockwise path (`cpu.attention_forward_cpu`), like the reference (py:322-323).
+    scale * groups must not exceed 87 when l2norm_qk is set (see the module docstring)."""
+    if q.device.type == "cpu":
+        return _cpu.attention_forward_cpu(q, k, v, mask=mask, attn_bias=attn_bias, scale=scale, groups=groups, causal=causal,
+                                          l2norm_qk=l2norm_qk, attn_bias_batch_dim=attn_bias_batch_dim)
     return flash_cosine_sim_attention_hip(q, k, v, mask, attn_bias, scale, groups, causal, l2norm_qk,
                                           attn_bias_batch_dim)

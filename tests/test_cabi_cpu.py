@@ -145,15 +145,16 @@ def test_debug_string(lib):
     assert b"gfx950" in buf.value and b"bf16" in buf.value
 
 
-def test_host_canonicalisation_rejects_bad_inputs_on_cpu():
+def test_gpu_entry_points_reject_cpu_tensors():
+    """The HIP path never falls back: the C-ABI glue refuses host tensors (CPU tensors are served by the operator's own
+    forward-only host path instead, see tests/test_cpu_path.py)."""
     import torch
-    import flash_cosine_sim_attention_amd as F
-    from flash_cosine_sim_attention_amd import _core
+    from flash_cosine_sim_attention_amd import _core, ops
     q = torch.randn(1, 2, 8, 64)
     with pytest.raises(RuntimeError, match="GPU"):
-        F.flash_cosine_sim_attention(q, q, q)
-    with pytest.raises(RuntimeError, match="GPU"):
         _core.attention_forward(q, q, q)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.flash_cosine_sim_attention_hip(q, q, q, None, None, 8, 1, False, True, False)
 
 
 def test_public_api_names_and_signature():

@@ -255,8 +255,12 @@ def test_error_behaviour():
         F.flash_cosine_sim_attention(bad, bad, bad)
     with pytest.raises(TypeError):
         F.flash_cosine_sim_attention(q, q.float(), q)
-    with pytest.raises(RuntimeError):
-        F.flash_cosine_sim_attention(q.cpu(), q.cpu(), q.cpu())
+    with pytest.raises(ValueError):            # tensors on different devices are refused, not dereferenced
+        F.flash_cosine_sim_attention(q, q.cpu(), q)
+    with pytest.raises(ValueError):
+        F.flash_cosine_sim_attention(q, q, q, mask=torch.ones(1, 8, dtype=torch.bool))
+    with pytest.raises(RuntimeError):          # the CPU path is forward-only (flash_cosine_sim_attention.py:142-144)
+        F.flash_cosine_sim_attention(q.cpu().float().requires_grad_(), q.cpu().float(), q.cpu().float())
 
 
 def test_no_grad_path_skips_saved_state():
