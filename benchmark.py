@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--num-times", default=20, type=int)
     ap.add_argument("--dtypes", default="float32,float16,bfloat16")
     ap.add_argument("--json", default=None, help="also write the table as JSON to this path")
+    ap.add_argument("--seq-lens", type=int, nargs="+", default=list(SEQ_LENS), help="sequence lengths (default: the reference's sweep)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         sys.exit("a GPU must be available to run the benchmark")
@@ -80,7 +81,7 @@ def main():
         w = torch.randn(BATCH, HEADS, 256, DIM, dtype=dtype, device="cuda", requires_grad=True)
         flash_cosine_sim_attention(w, w, w, causal=args.causal).sum().backward()
         torch.cuda.synchronize()
-        for seq in SEQ_LENS:
+        for seq in args.seq_lens:
             q, k, v = (torch.randn(BATCH, HEADS, seq, DIM, dtype=dtype, device="cuda").requires_grad_(backwards) for _ in range(3))
             mask = None
             if args.mask_prob > 0:

@@ -86,7 +86,7 @@ class _on_device:
 
 
 def _canonicalise(q, k, v, mask, attn_bias, attn_bias_batch_dim, causal):
-    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+    if not q.is_cuda:
         raise RuntimeError("flash_cosine_sim_attention_amd: q, k, v must be GPU tensors (HIP kernels only, no CPU fallback)")
     for name, t in (("k", k), ("v", v), ("mask", mask), ("attn_bias", attn_bias)):
         if t is not None and t.device != q.device:

@@ -739,14 +739,6 @@ namespace fcsa {
 #endif
 
 // ---------------------------------------------------------------------------------------------
-template <typename K>
-static hipError_t set_lds_once(K kern, size_t lds, bool& done) {
-  if (done) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess) done = true;
-  return e;
-}
-
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
 static int tile_waves(int64_t batch_heads, int len, bool causal) {
   const int MT = (len + 255) / 256;
@@ -762,8 +754,8 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   size_t lds = 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K stage + V stage)
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
-  static bool attr_set = false;
-  if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
+  static std::atomic<uint64_t> lds_ok{0};
+  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
@@ -787,8 +779,8 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 16);      // 2 x [Q tile | dO tile | per-query terms]
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
-  static bool attr_set = false;
-  if (hipError_t e = set_lds_once(kern, lds, attr_set); e != hipSuccess) return e;
+  static std::atomic<uint64_t> lds_ok{0};
+  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }

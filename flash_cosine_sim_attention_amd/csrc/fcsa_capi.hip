@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -166,14 +167,12 @@ int launch_check(hipError_t e, const char* what) {
 // ---- optional per-kernel timing (fcsa_profile_*) -------------------------------------------------
 struct TimedLaunch { const char* name; hipEvent_t start, stop; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};       // read lock-free on every launch; the mutex only guards the record list
 std::vector<TimedLaunch> g_prof;
 
 // run one kernel launch, bracketed by events on ITS stream when profiling is enabled
 template <typename F> int timed(const char* name, const char* what, hipStream_t s, F&& launch) {
-  bool on;
-  { std::lock_guard<std::mutex> g(g_prof_mu); on = g_prof_on; }
-  if (!on) return launch_check(launch(), what);
+  if (!g_prof_on.load(std::memory_order_relaxed)) return launch_check(launch(), what);
   TimedLaunch t{name, nullptr, nullptr};
   if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess)
     return fail(FCSA_ERR_LAUNCH, "%s: hipEventCreate failed", what);
@@ -191,8 +190,7 @@ extern "C" {
 const char* fcsa_last_error(void) { return g_err.c_str(); }
 
 int fcsa_profile_enable(int32_t enable) {
-  std::lock_guard<std::mutex> g(g_prof_mu);
-  g_prof_on = enable != 0;
+  g_prof_on.store(enable != 0, std::memory_order_relaxed);
   return FCSA_OK;
 }
 

@@ -844,12 +844,8 @@ static hipError_t launch_fwd2(const FwdParams& p, hipStream_t s) {
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   const size_t lds = 4 * 64 * TileGeom<D, 2>::ROWB;
   auto kern = fwd2_kernel<T, D, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
@@ -909,12 +905,8 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K tile + V tile) of 64 keys
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = fwd_kernel<T, D, NW, BIAS, DYN>;
-  static bool attr_set = false;                  // per instantiation; the attribute is sticky
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT), (unsigned)(p.splits > 1 ? p.splits : 1)), dim3(NW * 64), lds, s, p);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (p.splits > 1) {

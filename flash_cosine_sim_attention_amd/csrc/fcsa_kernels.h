@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace fcsa {
 
@@ -77,6 +78,19 @@ struct NormBwdParams {      // dx = reduce_heads(slab) then (optionally) l2norm 
   float eps;
   float xn_scale;           // x^ = xn_scale * xn   (1/c1 when xn was written with out_scale = c1)
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: raise it once per (instantiation, device).
+// `done` is the instantiation's bit mask of devices that have it (one static per launcher); thread safe, idempotent.
+template <typename K>
+static inline hipError_t ensure_dynamic_lds(K kern, size_t lds, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const uint64_t bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;        // devices >= 64: set it on every launch
+  if (bit != 0 && (done.load(std::memory_order_acquire) & bit) != 0) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess && bit != 0) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 // dtype: 1 = f16, 2 = bf16 (fcsa_dtype); returns hipError_t of the launch
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
