@@ -30,15 +30,11 @@ def forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal):
 
 
 def backward(d_out, o, inv_l, q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal):
-    q4, k4, v4, mask_c, bias_c, bias_batch, merged, dims = _core._canonicalise(
-        q, k, v, mask, attn_bias, attn_bias_batch_dim, causal)
-    o4 = o.unsqueeze(1) if o.dim() == 3 else o
-    saved = _core.Saved(_core._prep(o4), inv_l.reshape(dims[0], dims[1], dims[3]).contiguous(),
-                        _core._prep(q4), _core._prep(k4), _core._prep(v4), mask_c, bias_c,
-                        None, None, None, None, float(scale), 1, bool(causal), False, bool(bias_batch))
-    dq, dk, dv, db = _core.attention_backward(d_out, saved, q.shape, k.shape, v.shape,
-                                              need_bias_grad=attn_bias is not None)
-    return dq, dk, dv, db
+    empty = q.new_empty((0,))
+    empty32 = q.new_empty((0,), dtype=torch.float32)
+    saved = _core.Saved(o, inv_l, q, k, v, mask, attn_bias, empty, empty, empty32, empty32, float(scale), 1, bool(causal), False,
+                        bool(attn_bias_batch_dim))
+    return _core.attention_backward(d_out, saved, need_bias_grad=attn_bias is not None)
 
 
 def debug():

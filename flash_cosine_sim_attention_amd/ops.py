@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 from torch.autograd import Function
 
-from . import _core
+from . import _torch_ops
 from . import cpu as _cpu
 
 
@@ -92,30 +92,34 @@ def plain_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, grou
 # ---------------------------------------------------------------------------------------------
 
 class FlashCosineSimAttention(Function):
+    """Thin autograd.Function over the compiled dispatcher ops `torch.ops.fcsa.forward / backward` (csrc/fcsa_torch.cpp):
+    one call each, no Python-side marshalling; traceable by torch.compile (fake kernels in _torch_ops.py)."""
+
     @staticmethod
     def forward(ctx, q, k, v, mask, attn_bias, scale, groups, causal, l2norm_qk, attn_bias_batch_dim):
-        should_backwards = any(t is not None and t.requires_grad for t in (q, k, v, attn_bias))     # cu:1689
-        o, saved = _core.attention_forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal,
-                                           l2norm_qk=l2norm_qk, groups=groups, need_backward=should_backwards)
+        if not q.is_cuda:
+            raise RuntimeError("flash_cosine_sim_attention_amd: q, k, v must be GPU tensors (HIP kernels only, no CPU fallback)")
+        fc = _torch_ops.load()
+        should_backwards = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 4))              # q, k, v, attn_bias (cu:1689)
+        o, inv_l, qn, kn, rq, rk = fc.forward(q, k, v, mask, attn_bias, bool(attn_bias_batch_dim), float(scale), bool(causal),
+                                              bool(l2norm_qk), int(groups), should_backwards)
         ctx.should_backwards = should_backwards
         if not should_backwards:
             return o
         # tensors go through save_for_backward (py:270): no reference cycle through ctx, in-place modification of a saved
         # input is detected, saved-tensor hooks (checkpointing, offload) apply; scalars stay plain attributes
-        ctx.save_for_backward(saved.o, saved.inv_l, saved.q, saved.k, saved.v, saved.mask, saved.attn_bias,
-                              saved.qn, saved.kn, saved.rq, saved.rk)
-        ctx.scalars = (saved.scale, saved.groups, saved.causal, saved.l2norm_qk, saved.attn_bias_batch_dim)
-        ctx.shapes = (q.shape, k.shape, v.shape)
-        ctx.bias_grad = attn_bias is not None and attn_bias.requires_grad
+        ctx.save_for_backward(o, inv_l, q, k, v, mask, attn_bias, qn, kn, rq, rk)
+        ctx.scalars = (bool(attn_bias_batch_dim), float(scale), bool(causal), bool(l2norm_qk), int(groups))
+        ctx.bias_grad = bool(attn_bias is not None and ctx.needs_input_grad[4])
         return o
 
     @staticmethod
     def backward(ctx, do):
         assert ctx.should_backwards
-        q_shape, k_shape, v_shape = ctx.shapes
-        saved = _core.Saved(*ctx.saved_tensors, *ctx.scalars)
-        dq, dk, dv, db = _core.attention_backward(do, saved, q_shape, k_shape, v_shape, ctx.bias_grad)
-        return dq, dk, dv, None, db, None, None, None, None, None
+        o, inv_l, q, k, v, mask, attn_bias, qn, kn, rq, rk = ctx.saved_tensors
+        dq, dk, dv, db = _torch_ops.load().backward(do, o, inv_l, q, k, v, mask, attn_bias, qn, kn, rq, rk, *ctx.scalars,
+                                                    ctx.bias_grad)
+        return dq, dk, dv, None, (db if ctx.bias_grad else None), None, None, None, None, None
 
 
 flash_cosine_sim_attention_hip = FlashCosineSimAttention.apply

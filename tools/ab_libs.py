@@ -20,16 +20,21 @@ do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
 def step():
     q.grad = k.grad = v.grad = None
     F.flash_cosine_sim_attention(q, k, v, causal=bool(causal)).backward(do)
-libs = {}
+import ctypes
+from flash_cosine_sim_attention_amd import _torch_ops
+_torch_ops.load()
+binding = ctypes.CDLL(_torch_ops.BINDING_PATH)          # same loaded object as the dispatcher ops use
+libs, paths = {}, {}
 pkg = os.path.join(ROOT, "flash_cosine_sim_attention_amd")
 for t in a.tags:
     _lib._lib = None
-    _lib.LIB_PATH = os.path.join(pkg, "libfcsa_hip.so" if t == "main" else f"libfcsa_hip_{t}.so")
-    libs[t] = _lib.load()
+    _lib.LIB_PATH = paths[t] = os.path.join(pkg, "libfcsa_hip.so" if t == "main" else f"libfcsa_hip_{t}.so")
+    libs[t] = _lib.load()                                # ctypes handle of the same object: its profile hooks
 res = {t: {} for t in a.tags}
 for r in range(a.rounds + 1):
     for t in a.tags:
         _lib._lib = libs[t]
+        assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t      # route torch.ops.fcsa.* to this build
         for _ in range(3): step()
         torch.cuda.synchronize()
         _lib.profile_enable(True)
