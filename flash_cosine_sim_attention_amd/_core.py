@@ -55,6 +55,19 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
     return t if _rows_ok(t) else t.contiguous()
 
 
+# ---- ctypes helpers for code that drives the C ABI directly (tests, tools): struct builders over torch tensors ----
+
+def _tensor4(t: torch.Tensor) -> _lib.Tensor:
+    assert t.dim() == 4
+    return _lib.Tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _problem(dtype, dims, causal, bias_batch, l2norm_qk, groups, scale) -> _lib.Problem:
+    B, H, Hk, N, M, D = dims
+    return _lib.Problem(_DTYPES[dtype], B, H, Hk, N, M, D, int(bool(causal)), int(bool(bias_batch)),
+                        int(bool(l2norm_qk)), int(groups if l2norm_qk else 1), float(scale))
+
+
 def attention_forward(q, k, v, mask=None, attn_bias=None, attn_bias_batch_dim=False, scale=8.0, causal=False,
                       l2norm_qk=False, groups=1, need_backward=False) -> Tuple[torch.Tensor, Optional[Saved]]:
     """o = fused cosine-sim attention.  With l2norm_qk the (grouped) l2norm of q, k is done by the library.

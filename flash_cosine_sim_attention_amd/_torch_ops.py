@@ -47,6 +47,10 @@ def _register_fakes():
         rk = torch.empty((B, Hk, M, groups), **f32) if (l2norm_qk and need_backward) else none32
         return o, inv_l, qn, kn, rq, rk
 
+    @torch.library.register_fake("fcsa::attention")
+    def _(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal, l2norm_qk, groups):
+        return q.new_empty(q.shape)
+
     @torch.library.register_fake("fcsa::backward")
     def _(d_out, o, inv_l, q, k, v, mask, attn_bias, qn, kn, rq, rk, attn_bias_batch_dim, scale, causal, l2norm_qk, groups,
           need_bias_grad):

@@ -9,6 +9,7 @@
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
 #include <dlfcn.h>
@@ -228,6 +229,64 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> backward(const Tensor& d_out, const T
   return std::make_tuple(dq.reshape(q.sizes()), dk.reshape(k.sizes()), dv.reshape(v.sizes()), db);
 }
 
+// ---- autograd in C++ (reference: the Python autograd.Function FlashCosineSimAttention, flash_cosine_sim_attention.py:245-302).
+// A Python Function costs ~60 us of interpreter / engine hand-over per forward+backward; this node costs a few.  forward and
+// backward go through the dispatcher (fcsa::forward / fcsa::backward), so torch.compile traces them with the fake kernels.
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+struct AttentionFn : public torch::autograd::Function<AttentionFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask,
+                        const optional<Tensor>& attn_bias, bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk,
+                        int64_t groups) {
+    const bool bias_grad = attn_bias.has_value() && attn_bias->requires_grad();
+    const bool need = q.requires_grad() || k.requires_grad() || v.requires_grad() || bias_grad;                    // cu:1689
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("fcsa::forward", "")
+        .typed<std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const optional<Tensor>&,
+                                                                           const optional<Tensor>&, bool, double, bool, bool, int64_t, bool)>();
+    auto r = op.call(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal, l2norm_qk, groups, need);
+    if (need) {
+      ctx->save_for_backward({std::get<0>(r), std::get<1>(r), q, k, v, mask.has_value() ? *mask : Tensor(),
+                              attn_bias.has_value() ? *attn_bias : Tensor(), std::get<2>(r), std::get<3>(r), std::get<4>(r), std::get<5>(r)});
+      ctx->saved_data["bias_batch"] = attn_bias_batch_dim;
+      ctx->saved_data["scale"] = scale;
+      ctx->saved_data["causal"] = causal;
+      ctx->saved_data["l2norm_qk"] = l2norm_qk;
+      ctx->saved_data["groups"] = groups;
+      ctx->saved_data["bias_grad"] = bias_grad;
+    }
+    return std::get<0>(r);
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto s = ctx->get_saved_variables();
+    const optional<Tensor> mask = s[5].defined() ? optional<Tensor>(s[5]) : c10::nullopt;
+    const optional<Tensor> bias = s[6].defined() ? optional<Tensor>(s[6]) : c10::nullopt;
+    const bool bias_grad = ctx->saved_data["bias_grad"].toBool();
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("fcsa::backward", "")
+        .typed<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                          const optional<Tensor>&, const optional<Tensor>&, const Tensor&, const Tensor&,
+                                                          const Tensor&, const Tensor&, bool, double, bool, bool, int64_t, bool)>();
+    auto g = op.call(grads[0], s[0], s[1], s[2], s[3], s[4], mask, bias, s[7], s[8], s[9], s[10], ctx->saved_data["bias_batch"].toBool(),
+                     ctx->saved_data["scale"].toDouble(), ctx->saved_data["causal"].toBool(), ctx->saved_data["l2norm_qk"].toBool(),
+                     ctx->saved_data["groups"].toInt(), bias_grad);
+    return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor(), bias_grad ? std::get<3>(g) : Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor(), Tensor()};
+  }
+};
+
+Tensor attention_autograd(const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask, const optional<Tensor>& attn_bias,
+                          bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk, int64_t groups) {
+  return AttentionFn::apply(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal, l2norm_qk, groups);
+}
+
+// no autograd (inference / inputs that do not require grad): forward without saved state
+Tensor attention_plain(const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask, const optional<Tensor>& attn_bias,
+                       bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk, int64_t groups) {
+  return std::get<0>(forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal, l2norm_qk, groups, false));
+}
+
 }  // namespace
 
 // Measurement hook (not part of the operator surface): route the ops to another build of libfcsa_hip.so.  Returns 0 on success.
@@ -251,9 +310,17 @@ TORCH_LIBRARY(fcsa, m) {
   m.def("backward(Tensor d_out, Tensor o, Tensor inv_l, Tensor q, Tensor k, Tensor v, Tensor? mask, Tensor? attn_bias, Tensor qn, Tensor kn, "
         "Tensor rq, Tensor rk, bool attn_bias_batch_dim, float scale, bool causal, bool l2norm_qk, int groups, bool need_bias_grad) "
         "-> (Tensor, Tensor, Tensor, Tensor)");
+  // the operator itself: differentiable w.r.t. q, k, v, attn_bias (Autograd kernel below)
+  m.def("attention(Tensor q, Tensor k, Tensor v, Tensor? mask, Tensor? attn_bias, bool attn_bias_batch_dim, float scale, bool causal, "
+        "bool l2norm_qk, int groups) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(fcsa, CUDA, m) {       // ROCm builds of PyTorch dispatch HIP tensors under the CUDA key
   m.impl("forward", &forward);
   m.impl("backward", &backward);
+  m.impl("attention", &attention_plain);
+}
+
+TORCH_LIBRARY_IMPL(fcsa, Autograd, m) {
+  m.impl("attention", &attention_autograd);
 }
