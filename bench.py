@@ -43,6 +43,13 @@ def flops(w, fwd=True, bwd=True):
     return f * (causal_fraction(w["N"], w["M"]) if w["causal"] else 1.0)
 
 
+def lib_sha256():
+    """sha256 of the loaded libfcsa_hip.so: ties PMC measurements in profiles/ to the exact binary they were taken on."""
+    import hashlib
+    from flash_cosine_sim_attention_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+
+
 def aggregate_over_ranks(elapsed_s, flops_local, dist=None, device="cpu"):
     """Whole-job figures from per-rank ones: time = MAX over ranks, work = SUM over ranks (replicas, no data-path
     collective).  Returns (elapsed_max_s, flops_total).  `dist` is torch.distributed (initialised) or None."""
@@ -148,15 +155,44 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_gflop_per_launch": round(alg[dom["name"]] / 1e9, 2),
                         "timing": "hipEvent pairs recorded by libfcsa_hip on the launch stream over %d steps" % isteps}
-            # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the value is
-            # the committed measurement of this same command (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes,
-            # FETCH_SIZE x2 gfx950 correction), if one has been recorded for this round.
-            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the value is the
+            # committed measurement of this same command (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE x2
+            # gfx950 correction) -- but ONLY if it was taken on the very library binary that is loaded now (sha256 recorded by
+            # the PMC run); after any kernel change it reads null until the PMC passes are repeated.
+            tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
             if os.path.exists(tfile):
-                tk = json.load(open(tfile)).get("kernels", {}).get(dom["name"] + "_kernel")
-                if tk:
+                rec = json.load(open(tfile))
+                tk = rec.get("kernels", {}).get(dom["name"] + "_kernel")
+                if tk and rec.get("lib_sha256") == lib_sha256():
                     roofline["traffic"] = round(tk["total_bytes"])
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+                    roofline["traffic_source"] = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; "
+                                                  "same libfcsa_hip.so sha256 %s)" % rec["lib_sha256"][:12])
+                else:
+                    roofline["traffic_source"] = "null: profiles/r02_pmc_traffic.json was measured on a different build of libfcsa_hip.so"
+
+    # ---- stock softmax flash attention on the same box, shape, dtype, causal flag (the ">= 1.2x" target) -------
+    sdpa = None
+    if rank == 0:
+        qs, ks, vs = (t.detach().clone().requires_grad_() for t in (q, k, v))
+
+        def sdpa_step():
+            qs.grad = ks.grad = vs.grad = None
+            torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=w["causal"]).backward(do)
+
+        try:
+            for _ in range(10):
+                sdpa_step()
+            torch.cuda.synchronize()
+            n_sd = min(args.steps, 50)
+            t1 = time.perf_counter()
+            for _ in range(n_sd):
+                sdpa_step()
+            torch.cuda.synchronize()
+            sd_ms = (time.perf_counter() - t1) / n_sd * 1e3
+            sdpa = {"ms_per_step": round(sd_ms, 4), "tflops": round(flops(w) / (sd_ms * 1e-3) / 1e12, 2), "steps": n_sd,
+                    "what": "torch.nn.functional.scaled_dot_product_attention fwd+bwd, same tensors / dtype / causal flag, same FLOP convention"}
+        except Exception as e:                                   # pragma: no cover
+            sdpa = {"error": repr(e)[:200]}
 
     # ---- max |delta| vs a PyTorch f32 evaluation of the same math on (b,h) slices ----------------------
     max_delta = None
@@ -172,7 +208,7 @@ def main():
                 md = max(md, (o[b, h].float() - ref).abs().max().item())
             max_delta = md
 
-    # ---- CPU baseline: the PyTorch port of the reference's plain attention on the host cores -----------
+    # ---- CPU baseline: ports of the reference's CPU-runnable paths on the host cores, bounded samples ----------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_cpu_port as P
@@ -182,6 +218,15 @@ def main():
         cpu = {"value": round(flops(wf) / secs / 1e12, 4), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
                "kind": "port", "sample": "1 of 4 batch elements of the workload: (1,8,4096,64) bf16 causal fwd+bwd, "
                "PyTorch CPU port of plain_cosine_sim_attention + autograd, best of 2 after 1 warm-up (%.2f s)" % secs}
+        # second leg: the reference's tiled CPU forward ("reference CPU path", py:130-241), forward only, same sample
+        t_tiled = P.time_forward(P.tiled_forward_cpu, sample, sample, dt, w["causal"], reps=2, scale=w["scale"])
+        cpu["tiled_forward"] = {"value": round(flops(wf, bwd=False) / t_tiled / 1e12, 4), "unit": "TFLOP/s", "seconds": round(t_tiled, 3),
+                                "sample": "(1,8,4096,64) bf16 causal forward, port of the reference's tiled CPU path (512 x 512 tiles, f32 inside)"}
+        # third leg: BASELINE config C1, the reference's own CPU-runnable case: plain attention forward, (1,8,1024,64) f32
+        c1 = dict(B=1, H=8, N=1024, M=1024, D=64, causal=False)
+        t_c1 = P.time_forward(P.plain_attention_cpu, (1, 8, 1024, 64), (1, 8, 1024, 64), torch.float32, False, reps=3, scale=8.0)
+        cpu["c1_plain_forward"] = {"value": round(flops(c1, bwd=False) / t_c1 / 1e12, 4), "unit": "TFLOP/s", "seconds": round(t_c1, 4),
+                                   "sample": "C1: plain_cosine_sim_attention port, forward, (1,8,1024,64) f32 non-causal, best of 3"}
 
     if rank == 0:
         out = {
@@ -195,6 +240,8 @@ def main():
                        "algorithmic_gflop_per_step_per_gpu": round(flops(w) / 1e9, 2)},
             "max_abs_delta_vs_pytorch_f32": max_delta,
             "roofline": roofline,
+            "vs_flash_sdpa": (round(sdpa["ms_per_step"] / ms_per_step, 3) if sdpa and "ms_per_step" in sdpa else None),
+            "flash_sdpa": sdpa,
             "cpu_baseline": cpu,
             "kernels": kernels,
         }

@@ -141,3 +141,21 @@ def test_cpu_port_matches_numpy_oracle():
         assert np.abs(n(o) - ro).max() < 1e-10
         for a, r in ((q.grad, rdq), (k.grad, rdk), (v.grad, rdv)):
             assert np.abs(n(a) - r).max() < 1e-9
+
+
+def test_tiled_cpu_port_matches_numpy_oracle():
+    """oracle/torch_cpu_port.tiled_forward_cpu (a cpu_baseline leg of bench.py) == the numpy oracle's tiled path, incl. causal
+    N > tile (where the reference's own skip is wrong) and single-headed K/V with a key mask."""
+    import torch
+    from oracle import torch_cpu_port as P
+    torch.manual_seed(0)
+    q = torch.randn(2, 3, 150, 32)
+    k, v = torch.randn(2, 3, 150, 32), torch.randn(2, 3, 150, 32)
+    o = P.tiled_forward_cpu(q, k, v, causal=True, row_tile=64, col_tile=32)
+    ref = O.plain_attention(q.double().numpy(), k.double().numpy(), v.double().numpy(), causal=True)
+    assert np.abs(o.double().numpy() - ref).max() < 2e-5
+    k1, v1 = torch.randn(2, 90, 32), torch.randn(2, 90, 32)
+    mask = torch.rand(2, 90) > 0.3
+    o = P.tiled_forward_cpu(q, k1, v1, mask=mask, groups=2, scale=4.0, row_tile=64, col_tile=32)
+    ref = O.plain_attention(q.double().numpy(), k1.double().numpy(), v1.double().numpy(), mask=mask.numpy(), groups=2, scale=4.0)
+    assert np.abs(o.double().numpy() - ref).max() < 2e-5

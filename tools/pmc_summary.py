@@ -45,7 +45,11 @@ def main():
             if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
                 rd, wr = mean(acc[k]["FETCH_SIZE"]) * 1024 * 2, mean(acc[k]["WRITE_SIZE"]) * 1024
                 tr[k] = dict(read_bytes=rd, write_bytes=wr, total_bytes=rd + wr)
-        json.dump(dict(note="HBM bytes per launch on the bench workload (C3); FETCH_SIZE KiB x1024 x2 (gfx950 half-count "
+        import hashlib
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        lib = os.path.join(here, "flash_cosine_sim_attention_amd", "libfcsa_hip.so")
+        sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+        json.dump(dict(lib_sha256=sha, note="HBM bytes per launch on the bench workload (C3); FETCH_SIZE KiB x1024 x2 (gfx950 half-count "
                             "correction), WRITE_SIZE KiB x1024; separate --pmc passes (tools/gpu_pmc.sh)", kernels=tr),
                   open(out, "w"), indent=1)
 
