@@ -34,8 +34,17 @@
 #ifndef FCSA_DKV_BMQ8
 #define FCSA_DKV_BMQ8 128      // staged query rows of the 8-wave dKV form
 #endif
+#ifndef FCSA_DKV_BMQ_WIDE
+#define FCSA_DKV_BMQ_WIDE 64   // staged query rows of the dKV kernel for 16-bit D >= 96 in the LDS-DMA form
+#endif
 #ifndef FCSA_DQ_2W_BYTES
 #define FCSA_DQ_2W_BYTES 128
+#endif
+#ifndef FCSA_DQ_PIPE
+#define FCSA_DQ_PIPE 1         // software-pipelined dQ tile where the kernel runs one wave per SIMD (16-bit D >= 96)
+#endif
+#ifndef FCSA_DQ_SUB_WIDE
+#define FCSA_DQ_SUB_WIDE 0      // measured: no gain from 128-key stages at one wave per SIMD
 #endif
 #ifndef FCSA_DQ_DMA
 #define FCSA_DQ_DMA 1          // K / V stages of the dQ kernel by LDS-DMA (16-bit types)
@@ -118,6 +127,77 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) dq[db] = second_mma<T, D>(dq[db], kt, 32 * jb, db, pb, fa);
   }
+}
+
+// Software-pipelined form of dq_tile (16-bit types, no bias), same idea as dkv_tile_pipe: every LDS request is issued one
+// stage before its consumer.  Per 32-key block:  M1 (S^T, dP^T chains from the K / V row fragments requested during the previous
+// block's M2) | T (transposed K fragments for dQ, requested behind the M1 MFMAs) | X (exp, dS, pack) | R (next block's row
+// fragments, interleaved with) M2 (dQ^T += K^T dS^T).  The state crosses tile boundaries inside an LDS stage.  Measured: no gain
+// at two waves per SIMD (D = 64: the partner wave already hides the latency), -x% at one wave per SIMD (D >= 96), where it is used.
+template <typename T, int D> struct DqPipe {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  u32x4 kfr[G::KS], vfr[G::KS];
+  int tile;                          // key tile whose block-0 fragments are in flight (-1: none)
+  FCSA_DEV void request(const char* kt, const char* vt, const FragAddr<T, D>& fa, int jb) {
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) { kfr[kk] = fa.row_frag(kt, 32 * jb, kk); vfr[kk] = fa.row_frag(vt, 32 * jb, kk); }
+  }
+};
+
+template <typename T, int D, bool MASKED>
+FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, const char* vnext, int next_tile, int t,
+                           const FragAddr<T, D>& fa, const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS],
+                           const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB],
+                           float lc, float delta, uint64_t word, uint32_t ncm, int i, int j0, int diff, DqPipe<T, D>& pp_) {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  typedef Traits<T> TR;
+  if (pp_.tile != t) pp_.request(kt, vt, fa, 0);        // first tile of a stage (or after skipped tiles): exposed request
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    uint32_t w = 0xffffffffu;
+    if constexpr (MASKED)
+      w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+    FCSA_FENCE();
+    // ---- M1
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = -delta; }     // lc = log2(inv_l) - c2 and -delta ride in as initial values
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.kfr[kk], qf[kk], s);
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(pp_.vfr[kk], dof[kk], dp);
+    // ---- T
+    u32x4 ktr[G::DB][2];
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) { ktr[db][0] = fa.tr_frag(kt, 32 * jb, db); ktr[db][1] = fa.tr_frag(kt, 32 * jb + 16, db); }
+    FCSA_FENCE();
+    // ---- X
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = fast_exp2(s[r]);
+      if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
+      s[r] = e * dp[r];               // dp already holds dP - delta
+    }
+    SecondB<T> pb;
+    pb.prep(s);
+    FCSA_FENCE();
+    // ---- R (branch-free: past the last tile of a stage the request reads a valid but unrelated LDS address and is re-issued
+    //      at the top of the next tile) interleaved with M2
+    if (jb == 0) pp_.request(kt, vt, fa, 1);
+    else pp_.request(knext, vnext, fa, 0);
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) {
+      dq[db] = TR::mfma32(ktr[db][0], pb.v[0], dq[db]);
+      dq[db] = TR::mfma32(ktr[db][1], pb.v[1], dq[db]);
+    }
+    constexpr int NM2 = 2 * G::DB, NR = 2 * G::KS;
+#pragma unroll
+    for (int m = 0; m < NM2; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM2 - 1) / NM2, 0);
+    }
+  }
+  pp_.tile = next_tile;
 }
 
 // SUB = 64-key tiles per LDS stage: 1, or 2 in the 8-wave form (one workgroup per CU has the LDS for 128-key stages).  The
@@ -252,6 +332,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     t_split = min(t_split, nt);
   }
 
+  DqPipe<T, D> pipe;
+  pipe.tile = -1;
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     for (int t = t_begin; t < t_end; ++t) {
@@ -281,7 +363,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
         }
       }
       FCSA_STAMP(ts, 1);
-      if constexpr (MASKED) {
+      if constexpr (FCSA_DQ_PIPE && TR::ES == 2 && !BIAS && D * TR::ES > FCSA_DQ_2W_BYTES) {      // one wave per SIMD only
+        bool skip = false;
+        if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);
+        const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
+        if (!skip) dq_tile_pipe<T, D, MASKED>(kcur, vcur, next_here ? kcur + TILE_B : kcur, next_here ? vcur + TILE_B : vcur,
+                                              next_here ? t + 1 : -1, t, fa, qf, dof, dq, lc, delta, word, ncm, i, j0, diff, pipe);
+      } else if constexpr (MASKED) {
         const bool skip = p.causal && (j0 > mw + 31 + diff);
         if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
       } else {
@@ -741,6 +829,9 @@ namespace fcsa {
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
 static int tile_waves(int64_t batch_heads, int len, bool causal) {
+#ifdef FCSA_FORCE_NW4      // A/B builds only
+  return 4;
+#endif
   const int MT = (len + 255) / 256;
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
@@ -750,7 +841,9 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  constexpr int SUB = NW == 8 ? 2 : 1;
+  // 128-key stages (one barrier per 128 keys) in the 8-wave form and, with LDS-DMA staging (no staging registers), also for the
+  // one-wave-per-SIMD configurations (16-bit D >= 96: one workgroup per CU, the LDS is there)
+  constexpr int SUB = (NW == 8 || (FCSA_DQ_SUB_WIDE && FCSA_DQ_DMA && Traits<T>::ES == 2 && D * Traits<T>::ES > FCSA_DQ_2W_BYTES)) ? 2 : 1;
   size_t lds = 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K stage + V stage)
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
@@ -773,7 +866,10 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BNK = 32 * NW;
   // staged query tile: 32 rows for wide feature rows (16-bit D >= 96, f32 D >= 64: VGPR budget of the staging registers),
   // else 64; 128 in the 8-wave form (one workgroup per CU: the LDS is there, and half the barriers per key tile: -4.5%)
-  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? 32 : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
+  // (the pipelined LDS-DMA form has no staging registers: wide rows can take deeper tiles too -> fragment prefetch across
+  //  blocks, fewer barriers)
+  constexpr bool DMA_FORM = FCSA_DKV_PIPE && FCSA_DKV_DMA && Traits<T>::ES == 2 && !BIAS;
+  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? FCSA_DKV_BMQ_WIDE : 32) : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 16);      // 2 x [Q tile | dO tile | per-query terms]
@@ -801,7 +897,10 @@ template <typename T, int D> static hipError_t launch_dkv_t(const BwdParams& p, 
 }
 
 #ifdef FCSA_DEV_ONLY      // development builds: one instantiation (bf16, D = 64) for quick compiles / ISA inspection
-#define FCSA_DISPATCH_D(FN, T) if (D == 64) return FN<BF16, 64>(p, s); return hipErrorInvalidValue;
+#ifndef FCSA_DEV_D
+#define FCSA_DEV_D 64
+#endif
+#define FCSA_DISPATCH_D(FN, T) if (D == FCSA_DEV_D) return FN<BF16, FCSA_DEV_D>(p, s); return hipErrorInvalidValue;
 #else
 #define FCSA_DISPATCH_D(FN, T)                      \
   switch (D) {                                      \

@@ -937,7 +937,10 @@ static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
 template <typename T>
 static hipError_t launch_fwd_d(int D, const FwdParams& p, hipStream_t s) {
 #ifdef FCSA_DEV_ONLY      // development builds: one instantiation (bf16, D = 64)
-  if constexpr (std::is_same<T, BF16>::value) { if (D == 64) return launch_fwd_t<T, 64>(p, s); }
+#ifndef FCSA_DEV_D
+#define FCSA_DEV_D 64
+#endif
+  if constexpr (std::is_same<T, BF16>::value) { if (D == FCSA_DEV_D) return launch_fwd_t<T, FCSA_DEV_D>(p, s); }
   return hipErrorInvalidValue;
 #else
   switch (D) {
