@@ -22,7 +22,8 @@
 // dkv then stages 128-row query tiles, half the barriers).
 //
 // 7 tile products instead of the reference's 5 (S and dP are recomputed in both kernels); results
-// are deterministic.  d_bias (optional path) is accumulated with f32 atomics like cu:1574-1576.
+// are deterministic, d_bias included (a workgroup owns its slice of d_bias and reduces the broadcast index itself: no atomics,
+// cf. cu:1574-1576).
 // As in the forward kernel, each kernel runs its unmasked tiles and its masked tiles in two
 // sequential loops with one straight-line body each (no accumulator copies at if/else joins).
 #include <type_traits>
@@ -115,12 +116,30 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       if constexpr (BIAS) x += bv[r];
       float e = fast_exp2(x);
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
-      const float ds = e * dp[r];        // dp already holds dP - delta
-      if constexpr (BIAS) {
-        const int j = jbase + crow(r, 0);
-        if (dbias_row != nullptr && j < p.M && ds != 0.f) atomicAdd(dbias_row + j, ds);   // cu:1574-1576
+      s[r] = e * dp[r];                  // dS; dp already holds dP - delta
+    }
+    if constexpr (BIAS) {                // d_bias += dS: rows owned by this lane alone (see bwd_dq_kernel), 4 consecutive keys per rq
+      if (dbias_row != nullptr) {
+        if ((p.M & 3) == 0) {            // 16-byte aligned groups (wave-uniform test)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int j = jbase + 8 * rq;
+            if (j < p.M) {
+              f32x4* g = reinterpret_cast<f32x4*>(dbias_row + j);
+              f32x4 a = *g;
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4) a[e4] += s[4 * rq + e4];
+              *g = a;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = jbase + crow(r, 0);
+            if (j < p.M) dbias_row[j] += s[r];
+          }
+        }
       }
-      s[r] = ds;
     }
     SecondB<T> pb;
     pb.prep(s);
@@ -221,24 +240,41 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   // causal: a workgroup takes the PAIR of row tiles (MT-1-pt, pt) -> constant work per workgroup (see fwd_kernel)
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  int bh, pt;
-  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
-  const int b = bh / p.H, h = bh % p.H;
+  // d_bias[h or b, i, j] = sum over the OTHER index (batch for a per-head bias, heads for a per-batch bias) of dS[b, h, i, j].
+  // The reference pushes every dS element through an f32 atomic (cu:1574-1576).  Here a workgroup OWNS (bias slice, row tile):
+  // it runs the reduced index sequentially (`red` loop) and adds each dS block to d_bias with plain read-modify-writes of rows
+  // only this wave ever touches -- deterministic, no atomics.  Without a d_bias request: one (batch, head) per workgroup.
+  const bool own_bias = BIAS && p.d_bias != nullptr;
+  const int n_red = own_bias ? (p.bias_batch ? p.H : p.B) : 1;
+  int owner, pt;
+  block_to_work(blockIdx.x, own_bias ? (p.bias_batch ? p.B : p.H) : p.B * p.H, PT, owner, pt);
   const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
-  const int diff = p.M - p.N;
+  // split-key launches (gridDim.y = p.dq_splits > 1; never causal / bias): this workgroup sees the keys [k_lo, k_lo + Mk) only and
+  // writes its partial dQ^ (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
+  // Like the forward's split (fcsa_fwd.hip), for grids whose row tiles cannot fill the chip.
+  int k_lo = 0, Mk = p.M;
+  if (p.dq_splits > 1) {
+    const int tps = ((p.M + BN - 1) / BN + p.dq_splits - 1) / p.dq_splits;      // 64-key tiles per split
+    k_lo = (int)blockIdx.y * tps * BN;
+    Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
+  }
+  const int diff = p.M - p.N - k_lo;
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
 #ifdef FCSA_TRACE
   const unsigned long long trace_t0 = trace_now();
 #endif
+  for (int red = 0; red < n_red; ++red) {
+  const int b = own_bias ? (p.bias_batch ? owner : red) : owner / p.H;
+  const int h = own_bias ? (p.bias_batch ? red : owner) : owner % p.H;
   for (int pass = 0; pass < npass; ++pass) {
   const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;
   const int i = mw + (lane & 31);
 
-  int last_key = p.M - 1;
+  int last_key = Mk - 1;
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
@@ -266,7 +302,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     if (i < p.N) {
       const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
       lc = __builtin_amdgcn_logf(p.inv_l[ridx]) - p.c2;     // v_log_f32 = log2
-      if (fa.hi == 0) p.delta[ridx] = delta;
+      if (fa.hi == 0 && blockIdx.y == 0) p.delta[ridx] = delta;
     }
   }
 
@@ -276,9 +312,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh;
-  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh;
-  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M : nullptr;
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
+  const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M + k_lo : nullptr;
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   float* dbias_row = nullptr;                     // only for real rows
   if constexpr (BIAS) {
@@ -304,13 +340,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   const int nst = (nt + SUB - 1) / SUB;
   if (nt > 0) {
     if constexpr (DMA) {
-      dk_.issue(kbase, p.k.sn, p.M, smem, wave);
-      dv_.issue(vbase, p.v.sn, p.M, smem + HALF_B, wave);
+      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
+      dv_.issue(vbase, p.v.sn, Mk, smem + HALF_B, wave);
     } else {
-      sk.load(kbase, p.k.sn, p.M);
-      sv.load(vbase, p.v.sn, p.M);
+      sk.load(kbase, p.k.sn, Mk);
+      sv.load(vbase, p.v.sn, Mk);
     }
-    if (mrow) mb = lane < p.M ? mrow[lane] : (uint8_t)0;
+    if (mrow) mb = lane < Mk ? mrow[lane] : (uint8_t)0;
     if constexpr (DMA) {
       dma_wait();
     } else {
@@ -327,7 +363,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 
   int t_split = 0;                                 // see fwd_kernel
   if (!BIAS && mrow == nullptr) {
-    t_split = p.M / BN;
+    t_split = Mk / BN;
     if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);
     t_split = min(t_split, nt);
   }
@@ -347,19 +383,19 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       FCSA_STAMP(ts, 0);
       uint64_t word = 0;
       if constexpr (MASKED) {     // consume the mask byte BEFORE issuing new loads (see fwd_kernel)
-        word = __ballot((j0 + lane) < p.M && mb != 0);
+        word = __ballot((j0 + lane) < Mk && mb != 0);
         if (mrow && t + 1 < nt) {
           const int key = j0 + BN + lane;
-          mb = key < p.M ? mrow[key] : (uint8_t)0;
+          mb = key < Mk ? mrow[key] : (uint8_t)0;
         }
       }
       if (sub == 0 && more) {       // the buffer of stage u + 1 was last read in stage u - 1, which ended with a barrier
         if constexpr (DMA) {
-          dk_.issue(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, p.M - (u + 1) * BNS, snxt, wave);
-          dv_.issue(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, p.M - (u + 1) * BNS, snxt + HALF_B, wave);
+          dk_.issue(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, Mk - (u + 1) * BNS, snxt, wave);
+          dv_.issue(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, Mk - (u + 1) * BNS, snxt + HALF_B, wave);
         } else {
-          sk.load(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, p.M - (u + 1) * BNS);
-          sv.load(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, p.M - (u + 1) * BNS);
+          sk.load(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, Mk - (u + 1) * BNS);
+          sv.load(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, Mk - (u + 1) * BNS);
         }
       }
       FCSA_STAMP(ts, 1);
@@ -401,7 +437,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     char* scr = smem + wave * EP::BYTES;
     const int rows_valid = p.N - mw;
     if (rows_valid > 0) {
-      char* dq0 = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)mw * p.dq.sn;
+      char* dq0 = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)mw * p.dq.sn + (int64_t)blockIdx.y * p.dq_split_stride;
       if (p.rq != nullptr) {      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
         const char* x0 = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)mw * p.q.sn;
         EP::store(scr, dq, p.scale, lane, dq0, p.dq.sn, rows_valid, false, x0, p.q.sn, p.q_scaled ? 1.f / p.c1 : 1.f,
@@ -413,6 +449,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
   }
   }   // pass
+  if (red + 1 < n_red) __syncthreads();      // next (batch, head): its prologue overwrites the staging buffers
+  }   // red
 #ifdef FCSA_TRACE
   if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_dq + 32 * wave, trace_now() - trace_t0);
 #endif
@@ -849,12 +887,15 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
+  // with a d_bias request a workgroup owns (bias slice, row tile) and loops over the reduced index itself (see the kernel)
+  const int64_t owners = (BIAS && p.d_bias != nullptr) ? (p.bias_batch ? p.B : p.H) : (int64_t)p.B * p.H;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(owners * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
+  if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4>(p, s);       // split-key path: 128-row tiles x key ranges
   if constexpr (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES) {
     if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8>(p, s);
   }

@@ -127,7 +127,21 @@ float rowsum_eps(const fcsa_problem& p) {
 struct BwdLayout {
   size_t delta, dq_slab, dk_slab, dv_slab, total;
   bool need_dq_slab, need_dk_slab, need_dv_slab, fuse_norm;
+  int dq_splits;          // > 1: split-key dQ kernel, dq_slab holds dq_splits partial slabs
 };
+
+// Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
+// workgroups for 256 CUs), the problem is not causal, has no bias (d_bias ownership) and every split keeps >= 512 keys.
+// Mirrors forward_splits: C4 (1 x 8 heads x 1024 queries, 8192 keys) goes from 64 to 256 workgroups.
+int backward_dq_splits(const fcsa_problem& p) {
+  if (p.causal) return 1;
+  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
+  if (wgs <= 0 || wgs >= 128) return 1;
+  int64_t s = (256 + wgs - 1) / wgs;
+  if (s > 16) s = 16;
+  if (s > p.k_len / 512) s = p.k_len / 512;
+  return s >= 2 ? (int)s : 1;
+}
 
 int log2_blocks_per_group(const fcsa_problem& p) {     // log2(group size / 8), or -1 if not a power of two of 8-blocks
   const int dg = p.dim_head / (p.groups > 0 ? p.groups : 1);
@@ -147,12 +161,13 @@ BwdLayout bwd_layout(const fcsa_problem& p) {
   // otherwise (odd group sizes) and for the head reduction of single-headed K/V the kernels write f32
   // slabs that the finalize kernel reduces / differentiates.
   L.fuse_norm = p.l2norm_qk != 0 && fusable_groups(p);
-  L.need_dq_slab = p.l2norm_qk != 0 && !L.fuse_norm;
+  L.dq_splits = backward_dq_splits(p);
+  L.need_dq_slab = (p.l2norm_qk != 0 && !L.fuse_norm) || L.dq_splits > 1;
   L.need_dk_slab = single || (p.l2norm_qk != 0 && !L.fuse_norm);
   L.need_dv_slab = single;
   size_t off = 0;
   L.delta = off;   off = align_up(off + qn * 4, 256);
-  L.dq_slab = off; off = align_up(off + (L.need_dq_slab ? qn * p.dim_head * 4 : 0), 256);
+  L.dq_slab = off; off = align_up(off + (L.need_dq_slab ? qn * p.dim_head * 4 * (size_t)L.dq_splits : 0), 256);
   L.dk_slab = off; off = align_up(off + (L.need_dk_slab ? kn * p.dim_head * 4 : 0), 256);
   L.dv_slab = off; off = align_up(off + (L.need_dv_slab ? kn * p.dim_head * 4 : 0), 256);
   L.total = off;
@@ -394,10 +409,24 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.v = view(a->v, es, single);
   bp.o = view(a->o, es);
   bp.d_out = view(a->d_out, es);
-  bp.dq_f32 = L.need_dq_slab;
+  // split-key dQ needs (batch, head) to be one flat index of the dq output (the finalize kernel sums the partial slabs per
+  // (batch * head) row block) and no bias; otherwise the unsplit kernel runs
+  const bool dq_flat = a->dq.stride0 == (int64_t)p.heads * a->dq.stride1;
+  const int dq_splits = (L.dq_splits > 1 && dq_flat && a->attn_bias == nullptr) ? L.dq_splits : 1;
+  const bool dq_slab = dq_splits > 1 || (p.l2norm_qk != 0 && !L.fuse_norm);
+  bp.dq_splits = dq_splits;
+  bp.dq_split_stride = (int64_t)p.q_len * p.dim_head * 4;
+  bp.dq_f32 = dq_slab;
   bp.dk_f32 = L.need_dk_slab;
   bp.dv_f32 = L.need_dv_slab;
-  bp.dq = L.need_dq_slab ? contiguous_view(ws + L.dq_slab, p.heads, p.q_len, p.dim_head, 4) : view(a->dq, es);
+  if (dq_splits > 1) {          // slab layout [batch * heads][split][N][D]: (b, h) block stride = splits * N * D floats
+    bp.dq.p = ws + L.dq_slab;
+    bp.dq.sn = (int64_t)p.dim_head * 4;
+    bp.dq.sh = (int64_t)dq_splits * p.q_len * p.dim_head * 4;
+    bp.dq.sb = (int64_t)p.heads * bp.dq.sh;
+  } else {
+    bp.dq = dq_slab ? contiguous_view(ws + L.dq_slab, p.heads, p.q_len, p.dim_head, 4) : view(a->dq, es);
+  }
   bp.dk = L.need_dk_slab ? contiguous_view(ws + L.dk_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dk, es);
   bp.dv = L.need_dv_slab ? contiguous_view(ws + L.dv_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dv, es);
   bp.inv_l = a->inv_l;
@@ -413,7 +442,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.scale = p.scale;
   bp.q_scaled = p.l2norm_qk ? 1 : 0;
   bp.G = p.groups; bp.lgm = L.fuse_norm ? log2_blocks_per_group(p) : 0; bp.norm_eps = 1e-12f;
-  bp.rq = L.fuse_norm ? a->norm.rq : nullptr;                       // fused: dq kernel writes the final dq
+  bp.rq = (L.fuse_norm && dq_splits <= 1) ? a->norm.rq : nullptr;    // fused: dq kernel writes the final dq
   bp.rk = (L.fuse_norm && !single) ? a->norm.rk : nullptr;          // fused: dkv kernel writes the final dk
 
   // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
@@ -425,7 +454,17 @@ int fcsa_backward(const fcsa_backward_args* a) {
   nb.D = p.dim_head;
   nb.B = p.batch;
   nb.xn_scale = 1.f;
-  if (L.need_dq_slab) {
+  if (dq_splits > 1) {          // sum the split slabs ("heads" of a flat (batch * head) batch), then the l2norm backward if any
+    nb.B = p.batch * p.heads;
+    nb.slab = ws + L.dq_slab; nb.slab_f32 = 1; nb.HS = dq_splits; nb.HO = 1; nb.L = p.q_len;
+    if (p.l2norm_qk) { nb.xn = static_cast<const char*>(a->norm.qn); nb.inv_norm = a->norm.rq; nb.G = p.groups; nb.xn_scale = 1.f / (p.scale * kLog2e); }
+    else             { nb.xn = nullptr; nb.inv_norm = nullptr; nb.G = 1; }
+    nb.dx = view(a->dq, es);
+    nb.dx.sb = nb.dx.sh;          // flat (batch * head) index: stride0 == heads * stride1 (checked above)
+    nb.dx.sh = 0;
+    if (int rc = timed("finalize", "finalize dq (splits)", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
+    nb.B = p.batch;
+  } else if (dq_slab) {
     nb.slab = ws + L.dq_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.heads; nb.L = p.q_len;
     nb.xn = static_cast<const char*>(a->norm.qn); nb.inv_norm = a->norm.rq; nb.G = p.groups;
     nb.xn_scale = 1.f / (p.scale * kLog2e);           // qn holds c1 * q^

@@ -46,6 +46,8 @@ struct BwdParams {
   const uint8_t* mask;
   const char* bias;
   float* d_bias;            // [Hb,N,M] f32 zero-initialised or nullptr
+  int dq_splits;            // > 1: the dQ kernel splits the KEY range over gridDim.y workgroups that write partial f32 slabs
+  int64_t dq_split_stride;  //      byte distance between the slabs of consecutive splits (dq then views slab 0)
   int B, H, N, M;
   int causal, bias_batch;
   float c1, c2, bias_c;

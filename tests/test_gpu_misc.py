@@ -143,3 +143,27 @@ def test_small_shape_host_overhead_is_bounded():
     torch.cuda.synchronize()
     per_step_ms = (time.perf_counter() - t0) / 200 * 1e3
     assert per_step_ms < 0.35, per_step_ms
+
+
+def test_dbias_is_deterministic_and_matches_autograd():
+    """d_bias without atomics: bitwise identical across runs, equal to torch.autograd of the composite; per-head and per-batch
+    bias, key length not a multiple of 4 (scalar read-modify-write path) and a multiple of 4 (vector path)."""
+    import flash_cosine_sim_attention_amd as F
+    for (b, h, n, m, batch_dim) in ((3, 4, 70, 130, False), (3, 4, 70, 131, False), (2, 5, 64, 96, True)):
+        torch.manual_seed(n + m)
+        q = torch.randn(b, h, n, 32, device="cuda", dtype=torch.float32)
+        k = torch.randn(b, h, m, 32, device="cuda", dtype=torch.float32)
+        v = torch.randn(b, h, m, 32, device="cuda", dtype=torch.float32)
+        do = torch.randn(b, h, n, 32, device="cuda", dtype=torch.float32)
+        bias = (0.3 * torch.randn(b if batch_dim else h, n, m, device="cuda")).requires_grad_()
+        grads = []
+        for _ in range(3):
+            bias.grad = None
+            F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, attn_bias_batch_dim=batch_dim).backward(do)
+            grads.append(bias.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+        bias.grad = None
+        F.plain_cosine_sim_attention(q.double(), k.double(), v.double(), attn_bias=bias.double(),
+                                     attn_bias_batch_dim=batch_dim).backward(do.double())
+        ref = bias.grad
+        assert ((grads[0].double() - ref).norm() / ref.norm()).item() <= 2e-5

@@ -11,9 +11,10 @@ import flash_cosine_sim_attention_amd as F
 CFG = {
     "C2": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype=torch.float16, causal=False, mask=False, scale=8, groups=1, bwd=False),
     "C3": dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.bfloat16, causal=True, mask=False, scale=8, groups=1, bwd=True),
-    "C4": dict(q=(1, 8, 1024, 64), kv=(1, 8, 8192, 64), dtype=torch.float16, causal=False, mask=True, scale=8, groups=1, bwd=False),
+    "C4": dict(q=(1, 8, 1024, 64), kv=(1, 8, 8192, 64), dtype=torch.float16, causal=False, mask=True, scale=8, groups=1, bwd=True),
     "C5": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, mask=False, scale=1, groups=8, bwd=True),
     "C3-f16-noncausal": dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.float16, causal=False, mask=False, scale=8, groups=1, bwd=True),
+    "C2-bias": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype=torch.float16, causal=False, mask=False, scale=8, groups=1, bwd=True, bias=True),
     "C3-d128": dict(q=(4, 8, 4096, 128), kv=(4, 8, 4096, 128), dtype=torch.bfloat16, causal=True, mask=False, scale=8, groups=1, bwd=True),
 }
 
@@ -43,11 +44,15 @@ for name in sel:
     do = torch.randn(c["q"], device="cuda", dtype=c["dtype"], generator=g)
     B, H, N, D = c["q"]; M = c["kv"][-2]
     unit = B * H * N * M * D * frac(N, M, c["causal"])
-    kw = dict(mask=mask, causal=c["causal"], scale=c["scale"], groups=c["groups"])
+    bias = None
+    if c.get("bias"):        # per-head bias with gradient (d_bias): reference test grid item, tests/test.py:32
+        bias = (0.5 * torch.randn((H, N, M), device="cuda", dtype=c["dtype"], generator=g)).requires_grad_()
+    kw = dict(mask=mask, attn_bias=bias, causal=c["causal"], scale=c["scale"], groups=c["groups"])
     def fwd():
         with torch.no_grad(): return F.flash_cosine_sim_attention(q, k, v, **kw)
     def fb():
         q.grad = k.grad = v.grad = None
+        if bias is not None: bias.grad = None
         F.flash_cosine_sim_attention(q, k, v, **kw).backward(do)
     t_f = timeit(fwd)
     r = dict(fwd_ms=round(t_f, 4), fwd_tflops=round(4 * unit / t_f / 1e9, 1))
@@ -59,6 +64,7 @@ for name in sel:
         if os.environ.get('NO_SDPA'): raise RuntimeError('sdpa skipped')
         ke, ve = (k, v) if k.dim() == 4 else (k[:, None].expand(B, H, M, D), v[:, None].expand(B, H, M, D))
         am = None if mask is None else mask[:, None, None, :].expand(B, 1, N, M)
+        if bias is not None: am = bias.detach()[None].expand(B, H, N, M)          # additive float mask (no bias gradient in SDPA)
         def sfwd():
             with torch.no_grad(): return torch.nn.functional.scaled_dot_product_attention(q, ke, ve, attn_mask=am, is_causal=c["causal"])
         def sfb():
