@@ -21,6 +21,11 @@ def load():
         raise ImportError(f"{BINDING_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C flash_cosine_sim_attention_amd/csrc`).  There is no non-HIP fallback for GPU tensors.")
     torch.ops.load_library(BINDING_PATH)
+    alt = os.environ.get("FCSA_LIB")          # measurement only: route the ops to another build of the same C ABI (A/B runs)
+    if alt:
+        import ctypes
+        if ctypes.CDLL(BINDING_PATH).fcsa_torch_use_library(alt.encode()) != 0:
+            raise ImportError(f"FCSA_LIB={alt}: not a loadable build of libfcsa_hip.so")
     _register_fakes()
     _loaded = True
     return torch.ops.fcsa

@@ -526,63 +526,47 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
 //         X(ib)  : ... and land during exp / pack
 //         R(ib+1): the next block's row fragments are requested (their registers died in M1), interleaved with ...
 //         M2(ib) : ... the dV / dK products
-//   * LDS traffic, not the matrix pipe, bounds this kernel: with every LDS read stubbed out it runs in 80 us instead of 141.
-//     A third of that traffic were the per-query terms (log2-normaliser and -delta: 32 floats per lane per block, read as
-//     8 broadcast ds_read_b128 = 8 KiB per wave per block to seed the S / dP accumulators).  They now ride in on the MATRIX
-//     pipe: the staging thread of query row i splits lc_i and -delta_i into three 16-bit pieces each (hi + mid + lo: 24+
-//     bits) and stores them as two 16-byte chunks; lane (i, hi) of a block reads ONE chunk (hi = 0: lc pieces, hi = 1:
-//     -delta pieces) and that register quad is the A operand of one extra k-step for S (B = ones in the k-slots of the hi = 0
-//     half, zeros elsewhere) and one for dP (B = ones in the hi = 1 half): S = lc (x) 1 + Q K^T, dP = -delta (x) 1 + dO V^T.
-//     +2 MFMAs per block (18 instead of 16), -7 KiB of LDS reads per block (17 instead of 24), 32 registers freed.
+//     The per-query terms (log2-normaliser and -delta) stay accumulator seeds read from LDS (8 broadcast ds_read_b128 per
+//     block).  Tried and dropped: feeding them through one extra MFMA k-step per chain (the staging thread splits each term into
+//     three 16-bit pieces; -7 KiB of LDS reads per block, +2 MFMAs): 2 % slower at D = 64 and D = 128 once the tiles arrive by
+//     LDS-DMA -- the matrix pipe, not the LDS, is the scarcer resource here.
 template <typename T, int D, int BMQ>
 struct DkvPipe {
   typedef TileGeom<D, Traits<T>::ES> G;
   u32x4 qa[G::KS], da[G::KS];      // A operands of the next S / dP chains
-  u32x4 aux;                       // per-query terms of the next block (see above)
+  f32x16 s, dp;                    // their accumulators, seeded with the log2-normaliser and -delta of the block's queries
 
-  // aux_lane: byte offset of this lane's chunk inside a block's aux area = hi * BMQ * 16 + (lane & 31) * 16
-  FCSA_DEV void request(const char* qt, const char* dot, const char* auxs, int aux_lane, const FragAddr<T, D>& fa, int ib) {
-    aux = *reinterpret_cast<const u32x4*>(auxs + aux_lane + ib * 32 * 16);
+  FCSA_DEV void request(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa, int ib) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 lc4 = *reinterpret_cast<const f32x4*>(lcs + 32 * ib + 8 * rq + 4 * fa.hi);
+      const f32x4 nd4 = *reinterpret_cast<const f32x4*>(dls + 32 * ib + 8 * rq + 4 * fa.hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[4 * rq + e] = lc4[e]; dp[4 * rq + e] = nd4[e]; }
+    }
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) { qa[kk] = fa.row_frag(qt, 32 * ib, kk); da[kk] = fa.row_frag(dot, 32 * ib, kk); }
   }
 };
 
-// x -> three 16-bit pieces whose f32 sum reproduces x to >= 24 bits (k-slots 0..2 of an aux chunk; slots 3..7 are zero)
-template <typename T> FCSA_DEV u32x4 split3(float x) {
-  typedef Traits<T> TR;
-  if constexpr (TR::ES == 4) { u32x4 z = {0u, 0u, 0u, 0u}; return z; } else {
-  const uint32_t p0 = TR::pack2(x, 0.f);
-  const float r1 = x - TR::lo(p0);
-  const uint32_t p1 = TR::pack2(r1, 0.f);
-  const float r2 = r1 - TR::lo(p1);
-  const uint32_t p2 = TR::pack2(r2, 0.f);
-  u32x4 c = {(p0 & 0xffffu) | (p1 << 16), p2 & 0xffffu, 0u, 0u};
-  return c;
-  }
-}
-
 template <typename T, int D, int BMQ, bool MASKED>
-FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const char* auxs, int aux_lane, const FragAddr<T, D>& fa,
+FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                             const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
-                            const u32x4& ones_s, const u32x4& ones_d,
                             f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
                             uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int NB = BMQ / 32;
   DkvPipe<T, D, BMQ> pp_;
-  pp_.request(qt, dot, auxs, aux_lane, fa, 0);
+  pp_.request(qt, dot, lcs, dls, fa, 0);
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
     uint32_t w = 0xffffffffu;
     if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
     FCSA_FENCE();
     if (ib == 1) FCSA_STAMP(ts, 2);
-    // ---- M1: S = lc (x) 1 + Q K^T, dP = -delta (x) 1 + dO V^T
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 s = TR::mfma32(pp_.aux, ones_s, zero);
-    f32x16 dp = TR::mfma32(pp_.aux, ones_d, zero);
+    // ---- M1: S = Q K^T + lc, dP = dO V^T - delta (the per-query terms are the accumulators' initial values)
+    f32x16 s = pp_.s, dp = pp_.dp;
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.qa[kk], kf[kk], s);
 #pragma unroll
@@ -616,7 +600,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const char* auxs, i
     FCSA_FENCE();
     if (ib == 1) FCSA_STAMP(ts, 4);
     // ---- R: next block's row fragments (their registers are dead now)
-    if (ib + 1 < NB) pp_.request(qt, dot, auxs, aux_lane, fa, ib + 1);
+    if (ib + 1 < NB) pp_.request(qt, dot, lcs, dls, fa, ib + 1);
     // ---- M2: dV^T += dO^T P, dK^T += Q^T dS
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
@@ -629,7 +613,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const char* auxs, i
       dk[db] = TR::mfma32(tq[db][1], db_.v[1], dk[db]);
     }
     if (ib + 1 < NB) {      // spread the R requests behind the first M2 MFMAs (hipcc otherwise sinks them below the products)
-      constexpr int NM2 = 4 * G::DB, NR = 1 + 2 * G::KS;
+      constexpr int NM2 = 4 * G::DB, NR = 8 + 2 * G::KS;
 #pragma unroll
       for (int m = 0; m < NM2; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                   // one MFMA
@@ -646,9 +630,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BMQ * G::ROWB;
-  // Q tile | dO tile | per-query terms: lc[BMQ] | -delta[BMQ] floats, or (pipelined form) two arrays of 16-byte chunks
   constexpr bool PIPE = FCSA_DKV_PIPE && Traits<T>::ES == 2 && !BIAS;
-  constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 16;          // (the float form uses the first 2 * BMQ * 4 bytes of the last part)
+  constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 4;                // Q tile | dO tile | lc[BMQ] | -delta[BMQ]
   static_assert(BMQ % 32 == 0 && BMQ <= NT, "query tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF_B]
 
@@ -703,10 +686,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
   const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
-  // B operands of the aux k-step (dkv_tile_pipe): ones in k-slots 0..2 of the hi = 0 half (S) / of the hi = 1 half (dP)
-  const u32x4 ones3 = {TR::kOne2, TR::kOne2 & 0xffffu, 0u, 0u}, none = {0u, 0u, 0u, 0u};
-  const u32x4 ones_s = fa.hi == 0 ? ones3 : none, ones_d = fa.hi == 1 ? ones3 : none;
-  const int aux_lane = fa.hi * BMQ * 16 + (lane & 31) * 16;
 
   f32x16 dk[G::DB], dv[G::DB];
 #pragma unroll
@@ -761,10 +740,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       sdo.store(buf + TILE_B, tid);
     }
     if (tid < BMQ) {
-      if constexpr (PIPE) {      // rows beyond N: a large negative (finite in f16) normaliser makes P exactly 0 there
-        reinterpret_cast<u32x4*>(buf + 2 * TILE_B)[tid] = split3<T>(row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -30000.f);
-        reinterpret_cast<u32x4*>(buf + 2 * TILE_B + BMQ * 16)[tid] = split3<T>(row_ok ? -dl_r : 0.f);
-      } else {
+      {
         // rows beyond N: lc = -inf makes P exactly 0 there
         reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -INFINITY;
         reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? -dl_r : 0.f;      // -delta
@@ -807,8 +783,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       if constexpr (PIPE) {
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
-        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, cur + 2 * TILE_B, aux_lane, fa, kf, vf, ones_s, ones_d, dk, dv,
-                                                    kmask, ncm, j, i0, diff, ts);
+        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
         if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
@@ -913,7 +888,7 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? FCSA_DKV_BMQ_WIDE : 32) : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
-  size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 16);      // 2 x [Q tile | dO tile | per-query terms]
+  size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);      // 2 x [Q tile | dO tile | lc | -delta]
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
   static std::atomic<uint64_t> lds_ok{0};

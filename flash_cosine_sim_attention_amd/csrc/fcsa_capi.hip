@@ -471,19 +471,25 @@ int fcsa_backward(const fcsa_backward_args* a) {
     nb.dx = view(a->dq, es);
     if (int rc = timed("finalize", "finalize dq", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
   }
+  fcsa::NormBwdParams nk = nb, nv = nb;
   if (L.need_dk_slab) {
-    nb.slab = ws + L.dk_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.kv_heads; nb.L = p.k_len;
-    nb.xn_scale = 1.f;
-    if (p.l2norm_qk) { nb.xn = static_cast<const char*>(a->norm.kn); nb.inv_norm = a->norm.rk; nb.G = p.groups; }
-    else             { nb.xn = nullptr; nb.inv_norm = nullptr; nb.G = 1; }
-    nb.dx = view(a->dk, es);
-    if (int rc = timed("finalize", "finalize dk", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
+    nk.slab = ws + L.dk_slab; nk.slab_f32 = 1; nk.HS = p.heads; nk.HO = p.kv_heads; nk.L = p.k_len;
+    nk.xn_scale = 1.f;
+    if (p.l2norm_qk) { nk.xn = static_cast<const char*>(a->norm.kn); nk.inv_norm = a->norm.rk; nk.G = p.groups; }
+    else             { nk.xn = nullptr; nk.inv_norm = nullptr; nk.G = 1; }
+    nk.dx = view(a->dk, es);
   }
   if (L.need_dv_slab) {
-    nb.slab = ws + L.dv_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.kv_heads; nb.L = p.k_len;
-    nb.xn = nullptr; nb.inv_norm = nullptr; nb.G = 1;
-    nb.dx = view(a->dv, es);
-    if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
+    nv.slab = ws + L.dv_slab; nv.slab_f32 = 1; nv.HS = p.heads; nv.HO = p.kv_heads; nv.L = p.k_len;
+    nv.xn = nullptr; nv.inv_norm = nullptr; nv.G = 1; nv.xn_scale = 1.f;
+    nv.dx = view(a->dv, es);
+  }
+  if (L.need_dk_slab && L.need_dv_slab) {      // single-headed K/V: both head reductions in one launch
+    if (int rc = timed("finalize", "finalize dk+dv", s, [&] { return fcsa::launch_l2norm_bwd_pair(p.dtype, nk, nv, s); })) return rc;
+  } else if (L.need_dk_slab) {
+    if (int rc = timed("finalize", "finalize dk", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nk, s); })) return rc;
+  } else if (L.need_dv_slab) {
+    if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nv, s); })) return rc;
   }
   return FCSA_OK;
 }

@@ -101,5 +101,6 @@ hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t
 hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s);
 hipError_t launch_l2norm_pair(int dtype, const NormParams& a, const NormParams& b, hipStream_t s);   // q and k in one grid
 hipError_t launch_l2norm_bwd(int dtype, const NormBwdParams& p, hipStream_t s);
+hipError_t launch_l2norm_bwd_pair(int dtype, const NormBwdParams& a, const NormBwdParams& b, hipStream_t s);   // two passes, one grid
 
 }  // namespace fcsa

@@ -159,10 +159,10 @@ __global__ void __launch_bounds__(256) l2norm_generic_kernel(const NormParams p)
 // finalize: head reduction (+ l2norm backward), group size multiple of 8 (or no norm)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) {
+FCSA_DEV void l2norm_bwd_rows(const NormBwdParams& p, int block) {
   RowMap m;
   const int64_t nrows = (int64_t)p.B * p.HO * p.L;
-  m.init(p.D, nrows);
+  m.init(p.D, nrows, block);
   const bool norm = p.xn != nullptr;
   const int dg = p.D / p.G, lpg = norm ? (dg >> 3) : 1;
   float g[8], xh[8];
@@ -206,6 +206,17 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) 
   }
   if (m.active)
     store8<T>(p.dx.p + (int64_t)b * p.dx.sb + (int64_t)h * p.dx.sh + (int64_t)l * p.dx.sn + m.c * 8 * Traits<T>::ES, g);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const NormBwdParams p) { l2norm_bwd_rows<T>(p, blockIdx.x); }
+
+// two finalize passes of one backward call in ONE grid (dk and dv of single-headed K/V: each is a short HBM-bound pass, a
+// second launch costs about as much as the pass itself): blocks [0, blocks_a) take `a`, the rest take `b`
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_pair_kernel(const NormBwdParams a, const NormBwdParams b, const int blocks_a) {
+  if ((int)blockIdx.x < blocks_a) l2norm_bwd_rows<T>(a, blockIdx.x);
+  else l2norm_bwd_rows<T>(b, blockIdx.x - blocks_a);
 }
 
 // finalize, any group size: one thread per (row, group)
@@ -304,6 +315,29 @@ hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s) {
   if (dtype == 2) return launch_l2norm_t<BF16>(p, s);
   if (dtype == 1) return launch_l2norm_t<F16>(p, s);
   if (dtype == 0) return launch_l2norm_t<F32>(p, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t launch_l2norm_bwd_pair_t(const NormBwdParams& a, const NormBwdParams& b, hipStream_t s) {
+  const int rows_per_block = 4 * (64 / (a.D / 8));
+  const int64_t ra = (int64_t)a.B * a.HO * a.L, rb = (int64_t)b.B * b.HO * b.L;
+  const int64_t ba = (ra + rows_per_block - 1) / rows_per_block, bb = (rb + rows_per_block - 1) / rows_per_block;
+  if (ba + bb == 0) return hipSuccess;
+  hipLaunchKernelGGL(l2norm_bwd_pair_kernel<T>, dim3((unsigned)(ba + bb)), dim3(256), 0, s, a, b, (int)ba);
+  return hipGetLastError();
+}
+
+// both passes in one launch when both can use the 16-byte row kernel (equal D; group size % 8 == 0 or no norm), else two launches
+hipError_t launch_l2norm_bwd_pair(int dtype, const NormBwdParams& a, const NormBwdParams& b, hipStream_t s) {
+  auto rows_ok = [](const NormBwdParams& p) { return p.xn == nullptr || (p.D / p.G) % 8 == 0; };
+  if (!rows_ok(a) || !rows_ok(b) || a.D != b.D) {
+    const hipError_t e = launch_l2norm_bwd(dtype, a, s);
+    return e != hipSuccess ? e : launch_l2norm_bwd(dtype, b, s);
+  }
+  if (dtype == 2) return launch_l2norm_bwd_pair_t<BF16>(a, b, s);
+  if (dtype == 1) return launch_l2norm_bwd_pair_t<F16>(a, b, s);
+  if (dtype == 0) return launch_l2norm_bwd_pair_t<F32>(a, b, s);
   return hipErrorInvalidValue;
 }
 
