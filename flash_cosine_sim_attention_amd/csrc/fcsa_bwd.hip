@@ -278,6 +278,26 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
+  // K / V stages: LDS-DMA for 16-bit types (no staging registers, no ds_write passes; see DmaStager), else through registers.
+  // The first stage is issued HERE, ahead of the Q / dO / O row loads and the delta reduction, so that its latency hides under
+  // them (the previous pass ended with a barrier: the buffers are free).
+  constexpr bool DMA = FCSA_DQ_DMA && TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
+  Stager<T, D, BNS, NT> sk, sv;
+  DmaStager<T, D, DMA ? BNS : 1024, NW> dk_, dv_;
+  if constexpr (DMA) {
+    dk_.init(p.k.sn, wave, lane);
+    dv_.init(p.v.sn, wave, lane);
+    if (nt > 0) {
+      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
+      dv_.issue(vbase, p.v.sn, Mk, smem + HALF_B, wave);
+    }
+  } else {
+    sk.init(p.k.sn, tid);
+    sv.init(p.v.sn, tid);
+  }
+
   // Q, dO fragments (B operands) and delta = <dO_i, O_i>  (replaces backward_preprocess, cu:1256-1335)
   u32x4 qf[G::KS], dof[G::KS];
   float delta = 0.f, lc = 0.f;
@@ -312,8 +332,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
-  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M + k_lo : nullptr;
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   float* dbias_row = nullptr;                     // only for real rows
@@ -325,24 +343,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 
   // stages u = t / SUB of SUB 64-key tiles: loads of stage u+1 are issued at the first tile of stage u, stored after its last
   // tile, one barrier per stage (double-buffered LDS)
-  // K / V stages: LDS-DMA for 16-bit types (no staging registers, no ds_write passes; see DmaStager), else through registers
-  constexpr bool DMA = FCSA_DQ_DMA && TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
-  Stager<T, D, BNS, NT> sk, sv;
-  DmaStager<T, D, DMA ? BNS : 1024, NW> dk_, dv_;
-  if constexpr (DMA) {
-    dk_.init(p.k.sn, wave, lane);
-    dv_.init(p.v.sn, wave, lane);
-  } else {
-    sk.init(p.k.sn, tid);
-    sv.init(p.v.sn, tid);
-  }
   uint8_t mb = 1;
   const int nst = (nt + SUB - 1) / SUB;
   if (nt > 0) {
-    if constexpr (DMA) {
-      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
-      dv_.issue(vbase, p.v.sn, Mk, smem + HALF_B, wave);
-    } else {
+    if constexpr (!DMA) {
       sk.load(kbase, p.k.sn, Mk);
       sv.load(vbase, p.v.sn, Mk);
     }
@@ -665,34 +669,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   int t0 = 0;
   if (p.causal) t0 = max(0, n0 - diff) / BMQ;
 
-  // K, V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T), kept for the whole loop
-  u32x4 kf[G::KS], vf[G::KS];
-  {
-    const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
-    const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j * p.v.sn;
-#pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      kf[kk] = z;
-      vf[kk] = z;
-      if (j < p.M) {
-        kf[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + fa.hi) * 16);
-        if (!p.q_scaled) kf[kk] = scale_frag<T>(kf[kk], p.c1);     // S = Q (c1 K)^T when the Q tile is plain q^
-        vf[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + fa.hi) * 16);
-      }
-    }
-  }
-  bool key_ok = j < p.M;
-  if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
-  const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
-
-  f32x16 dk[G::DB], dv[G::DB];
-#pragma unroll
-  for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
-
+  // (the first query tile is requested HERE, ahead of the K / V fragment loads, so that its latency hides under them; the
+  //  previous pass ended with a barrier: the buffers are free)
   const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
   const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
@@ -748,10 +726,37 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     }
   };
 
-  if (t0 < QT) {
-    load_tile(t0, smem);
-    store_tile(smem);
+  if (t0 < QT) load_tile(t0, smem);
+
+  // K, V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T), kept for the whole loop
+  u32x4 kf[G::KS], vf[G::KS];
+  {
+    const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
+    const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j * p.v.sn;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      kf[kk] = z;
+      vf[kk] = z;
+      if (j < p.M) {
+        kf[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + fa.hi) * 16);
+        if (!p.q_scaled) kf[kk] = scale_frag<T>(kf[kk], p.c1);     // S = Q (c1 K)^T when the Q tile is plain q^
+        vf[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + fa.hi) * 16);
+      }
+    }
   }
+  bool key_ok = j < p.M;
+  if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
+  const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
+
+  f32x16 dk[G::DB], dv[G::DB];
+#pragma unroll
+  for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  if (t0 < QT) store_tile(smem);
   __syncthreads();
   // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
   // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never

@@ -299,7 +299,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 #ifdef FCSA_TRACE
   const unsigned long long trace_t0 = trace_now();
 #endif
+#ifdef FCSA_TRACE
+  unsigned long long pass_marks[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  unsigned long long first_iter[2][2] = {{0, 0}, {0, 0}};      // duration of the first iteration of the [pass][unmasked, masked] loop
+#define FCSA_PASS_MARK(k) pass_marks[pass][k] = trace_now()
+#else
+#define FCSA_PASS_MARK(k) ((void)0)
+#endif
   for (int pass = 0; pass < npass; ++pass) {
+  FCSA_PASS_MARK(0);
   const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;                  // first query row of this wave
@@ -310,8 +318,31 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
+  // DMA form (16-bit types): tile t+1 goes global -> LDS by LDS-DMA (DmaStager: no staging registers, no ds_write passes), issued
+  // at the top of tile t into the buffer whose last reads finished before the barrier of tile t-1, and waited for right before
+  // the barrier of tile t.  The FIRST tile is issued here, ahead of the Q fragments and their fused l2norm, so that its
+  // HBM / L2 latency hides under that work (the previous pass ended with a barrier: the buffers are free).
+  constexpr bool DMA = FCSA_FWD_DMA && TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
+  constexpr bool EARLY = DMA && !DYN;             // (the dynamic-shift pre-pass stages through the same buffers first)
+  Stager<T, D, BN, NT> sk, sv;
+  DmaStager<T, D, DMA ? BN : 1024, NW> dk_, dv_;
+  if constexpr (DMA) {
+    dk_.init(p.k.sn, wave, lane);
+    dv_.init(p.v.sn, wave, lane);
+    if (EARLY && nt > 0) {
+      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
+      dv_.issue(vbase, p.v.sn, Mk, smem + TILE_B, wave);
+    }
+  } else {
+    sk.init(p.k.sn, tid);
+    sv.init(p.v.sn, tid);
+  }
+
   u32x4 qf[G::KS];
   load_q_frags<T, D>(p, b, h, i, fa, qf);
+  FCSA_PASS_MARK(1);
 
   f32x16 o[G::DB];
 #pragma unroll
@@ -323,8 +354,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 #pragma unroll
   for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
 
-  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
-  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M + k_lo : nullptr;
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   if constexpr (BIAS)
@@ -375,19 +404,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   //   mid()    : barrier (all LDS reads of tile t returned, tile t+1 visible), K fragment requests of tile t+1
   //   PV products of tile t
   // Buffer (t+1)&1 held tile t-1, whose last reads every wave completed before the barrier of t-1.
-  // DMA form (16-bit types): tile t+1 goes global -> LDS by LDS-DMA (DmaStager: no staging registers, no ds_write passes), issued
-  // at the top of tile t into the buffer whose last reads finished before the barrier of tile t-1, and waited for right before
-  // the barrier of tile t.
-  constexpr bool DMA = FCSA_FWD_DMA && TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
-  Stager<T, D, BN, NT> sk, sv;
-  DmaStager<T, D, DMA ? BN : 1024, NW> dk_, dv_;
-  if constexpr (DMA) {
-    dk_.init(p.k.sn, wave, lane);
-    dv_.init(p.v.sn, wave, lane);
-  } else {
-    sk.init(p.k.sn, tid);
-    sv.init(p.v.sn, tid);
-  }
   uint8_t mb = 1;
   u32x4 kf[2][G::KS];
   auto request_k = [&](const char* kt) {
@@ -398,8 +414,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   };
   if (nt > 0) {
     if constexpr (DMA) {
-      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
-      dv_.issue(vbase, p.v.sn, Mk, smem + TILE_B, wave);
+      if (!EARLY) {
+        dk_.issue(kbase, p.k.sn, Mk, smem, wave);
+        dv_.issue(vbase, p.v.sn, Mk, smem + TILE_B, wave);
+      }
     } else {
       sk.load(kbase, p.k.sn, Mk);
       sv.load(vbase, p.v.sn, Mk);
@@ -422,6 +440,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     }
   }
   __syncthreads();
+  FCSA_PASS_MARK(2);
   // K fragments of a tile are 8 * KS registers; 512-byte rows (f32, D = 128) cannot hold them across the PV products
   constexpr bool PREFETCH_K = D * TR::ES < 512;
   if (PREFETCH_K && nt > 0) request_k(smem);
@@ -438,6 +457,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     for (int t = t_begin; t < t_end; ++t) {
+#ifdef FCSA_TRACE
+      if (t == t_begin + 1) first_iter[pass][MASKED ? 1 : 0] = trace_now() - first_iter[pass][MASKED ? 1 : 0];
+      if (t == t_begin) first_iter[pass][MASKED ? 1 : 0] = trace_now();
+#endif
       const int j0 = t * BN;
       const char* vcur = smem + (t & 1) * 2 * TILE_B + TILE_B;
       char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
@@ -456,6 +479,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
           dk_.issue(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN), knxt, wave);
           dv_.issue(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, Mk - (j0 + BN), knxt + TILE_B, wave);
         }
+        FCSA_STAMP(ts, 1);
       } else {
         if (t + 1 < nt) {
           sk.store(knxt, tid);
@@ -487,6 +511,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   };
   run(std::false_type{}, 0, t_split);
   run(std::true_type{}, t_split, nt);
+  FCSA_PASS_MARK(3);
   // no trailing barrier: every wave completed its last LDS read before the final mid() barrier, so the next
   // pass may overwrite buffer 0 in its prologue
 
@@ -512,9 +537,17 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
                 p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     if (pass + 1 < npass) __syncthreads();
   }
+  FCSA_PASS_MARK(4);
   }   // pass
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_fwd + 32 * wave, trace_now() - trace_t0);
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (NW == 4 ? wave < 4 : (wave & 2) == 0)) {
+    unsigned long long* out = g_trace_fwd + 32 * (NW == 4 ? wave : (wave & 1) + 2 * (wave >> 2));
+    ts.dump(out, trace_now() - trace_t0);   // 8 waves: 0, 1, 4, 5
+    for (int ps = 0; ps < 2; ++ps)
+      for (int k = 0; k < 4; ++k) out[14 + 4 * ps + k] = pass_marks[ps][k + 1] - pass_marks[ps][k];   // Q frags | first tile | key loop | epilogue
+    out[22] = pass_marks[0][0] - trace_t0;
+    for (int ps = 0; ps < 2; ++ps) { out[23 + 2 * ps] = first_iter[ps][0]; out[24 + 2 * ps] = first_iter[ps][1]; }
+  }
 #endif
 }
 
