@@ -90,9 +90,10 @@ template <typename T, int D, bool MASKED, bool BIAS, typename Mid>
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, f32x16& lacc, const FwdParams& p, float c2row, uint64_t word, uint32_t ncm, int i, int j0, int diff,
-                       const char* bias_row, Trace& ts, Mid&& mid) {
+                       const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  constexpr bool PREFETCH_K = D * TR::ES < 512;     // see fwd_kernel
   // validity bits of this lane's 16 keys per block.  Branch-free and BEFORE the MFMA chains on purpose: a runtime
   // branch between the last MFMA and the first read of its result gets too few wait states on the
   // taken path (hipcc 7.2 pads only the fall-through; seen with the 16-pass v_mfma_f32_32x32x2_f32).
@@ -138,6 +139,16 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     FCSA_STAMP(ts, 4);
     mid();
     __builtin_amdgcn_sched_barrier(0);
+    // --- K fragment requests of the NEXT tile, scheduled among the PV products of block 0 instead of as a burst right behind
+    // the barrier (all eight waves bursting 8 ds_read_b128 there took 350 .. 770 ticks of a 2100-tick tile, phase trace; -1.5 %).
+    // Branch-free: past the last tile the reads hit the idle buffer and are never used.  (A fully slot-fenced form of this
+    // phase, as in fwd2_tile, measured no better than hipcc's own placement under these group hints.)
+    if constexpr (PREFETCH_K) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(knext, 32 * jb, kk);
+    }
     // --- PV of block 0 (row sum + DB output blocks) interleaved with exp / pack of block 1
     const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
     lacc = TR::mfma32(ones, pb0.v[0], lacc);
@@ -159,6 +170,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     for (int m = 0; m < NPV; ++m) {
       __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
       __builtin_amdgcn_sched_group_barrier(VALU, (MASKED ? 48 : 26) / NPV + 1, 0);
+      if constexpr (PREFETCH_K) __builtin_amdgcn_sched_group_barrier(DSR, (2 * G::KS + NPV - 1) / NPV, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     FCSA_STAMP(ts, 8);
@@ -205,6 +217,12 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       }
     }
     mid();
+    if (PREFETCH_K && more_k) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(knext, 32 * jb, kk);
+    }
   }
 }
 
@@ -361,27 +379,42 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 
   float c2row = p.c2;
   if constexpr (DYN) {
-    // plain (unpipelined) pass: this path only serves logit ranges no static exponent window can hold
+    // first pass over the K tiles: row max of the logits (S chains and masks only).  16-bit types: K tiles by LDS-DMA, double
+    // buffered, one barrier per tile (tile t+1 in flight while tile t is reduced); f32: through registers, two barriers per tile.
     float m2 = -INFINITY;
     Stager<T, D, BN, NT> s1;
-    s1.init(p.k.sn, tid);
+    if constexpr (!DMA) s1.init(p.k.sn, tid);
+    if constexpr (DMA) {
+      if (nt > 0) dk_.issue(kbase, p.k.sn, Mk, smem, wave);
+    }
     for (int t = 0; t < nt; ++t) {
       const int j0 = t * BN;
-      s1.load(kbase + (int64_t)j0 * p.k.sn, p.k.sn, Mk - j0);
-      __syncthreads();                     // readers of the previous tile are done
-      s1.store(smem, tid);
-      __syncthreads();
+      const char* kt = smem;
+      if constexpr (DMA) {
+        kt = smem + (t & 1) * TILE_B;
+        dma_wait();
+        __syncthreads();                     // tile t landed for everyone; every reader of tile t-1 is done
+        if (t + 1 < nt) dk_.issue(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN), smem + ((t + 1) & 1) * TILE_B, wave);
+      } else {
+        s1.load(kbase + (int64_t)j0 * p.k.sn, p.k.sn, Mk - j0);
+        __syncthreads();                     // readers of the previous tile are done
+        s1.store(smem, tid);
+        __syncthreads();
+      }
       const int key = min(j0 + lane, Mk - 1);
       const uint64_t word = __ballot((j0 + lane) < Mk && (mrow == nullptr || mrow[key] != 0));
       if (p.causal && j0 > mw + 31 + diff) continue;       // wave-uniform; the barriers above are still executed
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
         const uint32_t w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+        u32x4 kfr[G::KS];
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) kfr[kk] = fa.row_frag(kt, 32 * jb, kk);      // all requests first, then the chain
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(smem, 32 * jb, kk), qf[kk], s);
+        for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(kfr[kk], qf[kk], s);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float x = s[r];
@@ -492,19 +525,21 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
         }
       }
       FCSA_STAMP(ts, 2);
-      auto mid = [&]() {
+      auto mid = [&]() {          // every LDS read of this tile has been issued; publish tile t+1
         FCSA_STAMP(ts, 5);
         if constexpr (DMA) dma_wait();
         __syncthreads();
         FCSA_STAMP(ts, 6);
-        if (PREFETCH_K && t + 1 < nt) request_k(knxt);
-        FCSA_STAMP(ts, 7);
       };
       bool skip = false;
       if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
       if (!PREFETCH_K && !skip) request_k(vcur - TILE_B);
-      if (skip) mid();
-      else fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid);
+      if (skip) {
+        mid();
+        if (PREFETCH_K && t + 1 < nt) request_k(knxt);
+      } else {
+        fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt);
+      }
       FCSA_STAMP(ts, 10);
       if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only
     }
