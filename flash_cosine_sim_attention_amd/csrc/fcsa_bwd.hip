@@ -50,6 +50,12 @@
 #ifndef FCSA_DQ_DMA
 #define FCSA_DQ_DMA 1          // K / V stages of the dQ kernel by LDS-DMA (16-bit types)
 #endif
+#ifndef FCSA_DKV_EXP_UNDER_DP    // 1: pipelined dKV tile issues the exponentials of a block between the MFMAs of its dP chain (measured: +1.2 % time)
+#define FCSA_DKV_EXP_UNDER_DP 0
+#endif
+#ifndef FCSA_DKV_SPREAD      // 1: the LDS-DMA pieces of the next tile are issued one per 32-row block instead of all at the tile top (measured: +1.1 % time)
+#define FCSA_DKV_SPREAD 0
+#endif
 #ifndef FCSA_DKV_DMA
 #define FCSA_DKV_DMA 1         // Q / dO tiles of the pipelined dKV form by LDS-DMA (0: through registers, for A/B builds)
 #endif
@@ -110,11 +116,18 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
         bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
       }
     }
+    // (exponentials first, products second: a v_exp_f32 directly followed by the multiply that consumes it costs a hazard nop
+    //  plus the transcendental latency, and hipcc schedules the interleaved form that way under register pressure)
+    float pe[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float x = s[r];               // = c1 * qh.kh + lc already (c1 rides on q, lc is the accumulator's initial value)
       if constexpr (BIAS) x += bv[r];
-      float e = fast_exp2(x);
+      pe[r] = fast_exp2(x);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = pe[r];
       if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
       s[r] = e * dp[r];                  // dS; dp already holds dP - delta
     }
@@ -264,11 +277,16 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   ts.reset();
 #ifdef FCSA_TRACE
   const unsigned long long trace_t0 = trace_now();
+  unsigned long long pass_marks[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+#define FCSA_PASS_MARK(k) pass_marks[pass][k] = trace_now()
+#else
+#define FCSA_PASS_MARK(k) ((void)0)
 #endif
   for (int red = 0; red < n_red; ++red) {
   const int b = own_bias ? (p.bias_batch ? owner : red) : owner / p.H;
   const int h = own_bias ? (p.bias_batch ? red : owner) : owner % p.H;
   for (int pass = 0; pass < npass; ++pass) {
+  FCSA_PASS_MARK(0);
   const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;
@@ -285,13 +303,23 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   // them (the previous pass ended with a barrier: the buffers are free).
   constexpr bool DMA = FCSA_DQ_DMA && TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
   Stager<T, D, BNS, NT> sk, sv;
-  DmaStager<T, D, DMA ? BNS : 1024, NW> dk_, dv_;
+  typedef DmaStager<T, D, DMA ? BNS : 1024, NW> DS;
+  DS dk_, dv_;
+  typename DS::Stream stk, stv;       // K / V walked stage by stage from key k_lo (DMA form): one descriptor per pass
+  uint32_t k_step = 0, v_step = 0, lds0 = 0;
+  bool far = false;
   if constexpr (DMA) {
     dk_.init(p.k.sn, wave, lane);
     dv_.init(p.v.sn, wave, lane);
+    stk = dk_.open(kbase, p.k.sn, Mk);
+    stv = dv_.open(vbase, p.v.sn, Mk);
+    k_step = (uint32_t)(BNS * p.k.sn);
+    v_step = (uint32_t)(BNS * p.v.sn);
+    far = BNS * p.k.sn > (int64_t)DS::REBASE || BNS * p.v.sn > (int64_t)DS::REBASE;
+    lds0 = DS::lds_addr(smem);
     if (nt > 0) {
-      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
-      dv_.issue(vbase, p.v.sn, Mk, smem + HALF_B, wave);
+      dk_.issue(stk, lds0, wave);
+      dv_.issue(stv, lds0 + HALF_B, wave);
     }
   } else {
     sk.init(p.k.sn, tid);
@@ -395,8 +423,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       }
       if (sub == 0 && more) {       // the buffer of stage u + 1 was last read in stage u - 1, which ended with a barrier
         if constexpr (DMA) {
-          dk_.issue(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, Mk - (u + 1) * BNS, snxt, wave);
-          dv_.issue(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, Mk - (u + 1) * BNS, snxt + HALF_B, wave);
+          stk.off += k_step;
+          stv.off += v_step;
+          if (far || (stk.off | stv.off) > DS::REBASE) {      // 32-bit offsets about to run out: re-open at this stage
+            stk = dk_.open(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, Mk - (u + 1) * BNS);
+            stv = dv_.open(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, Mk - (u + 1) * BNS);
+          }
+          const uint32_t lds_nxt = lds0 + ((u + 1) & 1) * 2 * HALF_B;
+          dk_.issue(stk, lds_nxt, wave);
+          dv_.issue(stv, lds_nxt + HALF_B, wave);
         } else {
           sk.load(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, Mk - (u + 1) * BNS);
           sv.load(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, Mk - (u + 1) * BNS);
@@ -432,8 +467,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       if constexpr (!MASKED) ts.close(4);
     }
   };
+  FCSA_PASS_MARK(1);
   run(std::false_type{}, 0, t_split);
+  FCSA_PASS_MARK(2);
   run(std::true_type{}, t_split, nt);
+  FCSA_PASS_MARK(3);
 
   // Epilogue through the LDS (RowEpilogue): every stage ended with a barrier, so no wave still reads the staging buffers.
   {
@@ -452,11 +490,18 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     }
     if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
   }
+  FCSA_PASS_MARK(4);
   }   // pass
   if (red + 1 < n_red) __syncthreads();      // next (batch, head): its prologue overwrites the staging buffers
   }   // red
+#undef FCSA_PASS_MARK
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && wave < 4) ts.dump(g_trace_dq + 32 * wave, trace_now() - trace_t0);
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (wave & 2) == 0) {      // waves 0, 1, 4, 5
+    unsigned long long* out = g_trace_dq + 32 * ((wave & 1) + 2 * (wave >> 2));
+    ts.dump(out, trace_now() - trace_t0);
+    for (int ps = 0; ps < 2; ++ps)
+      for (int k = 0; k < 4; ++k) out[14 + 4 * ps + k] = pass_marks[ps][k + 1] - pass_marks[ps][k];   // prologue | unmasked tiles | masked tiles | epilogue
+  }
 #endif
 }
 
@@ -553,11 +598,11 @@ struct DkvPipe {
   }
 };
 
-template <typename T, int D, int BMQ, bool MASKED>
+template <typename T, int D, int BMQ, bool MASKED, typename Hook>
 FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                             const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                             f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts) {
+                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts, Hook&& hook) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int NB = BMQ / 32;
@@ -573,8 +618,10 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     f32x16 s = pp_.s, dp = pp_.dp;
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.qa[kk], kf[kk], s);
+#if !FCSA_DKV_EXP_UNDER_DP
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(pp_.da[kk], vf[kk], dp);
+#endif
     // ---- T: transposed fragments of this block (dO^T for dV, Q^T for dK)
     u32x4 td[G::DB][2], tq[G::DB][2];
 #pragma unroll
@@ -589,14 +636,28 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     }
     FCSA_FENCE();
     if (ib == 1) FCSA_STAMP(ts, 3);
-    // ---- X: P = exp2(s), dS = P * (dP - delta), packed in place
+    hook(ib);      // this block's share of the next tile's LDS-DMA requests
+    FCSA_FENCE();
+    // ---- X: P = exp2(s), dS = P * (dP - delta), packed in place.  The exponentials need S only: they are issued between the
+    //      MFMAs of the dP chain (same wave: the VALU works while the matrix pipe runs that chain), the products after it.
     f32x16 pr;
+#if FCSA_DKV_EXP_UNDER_DP
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(pp_.da[kk], vf[kk], dp);
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(s[r]);
+#if FCSA_DKV_EXP_UNDER_DP
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                   // one MFMA of the dP chain
+      __builtin_amdgcn_sched_group_barrier(0x400, (16 + G::KS - 1) / G::KS, 0);          // its share of the 16 exponentials
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float pe = fast_exp2(s[r]);
-      if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
-      pr[r] = pe;
-      s[r] = pe * dp[r];
+      if constexpr (MASKED) pr[r] = ((w >> crow(r, 0)) & 1u) ? pr[r] : 0.f;
+      s[r] = pr[r] * dp[r];
     }
     SecondB<T> pb, db_;
     pb.prep(pr);
@@ -657,8 +718,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   ts.reset();
 #ifdef FCSA_TRACE
   const unsigned long long trace_t0 = trace_now();
+  unsigned long long pass_marks[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+#define FCSA_PASS_MARK(k) pass_marks[pass][k] = trace_now()
+#else
+#define FCSA_PASS_MARK(k) ((void)0)
 #endif
   for (int pass = 0; pass < npass; ++pass) {
+  FCSA_PASS_MARK(0);
   const int kt = p.causal ? (pass == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
   const int n0 = kt * BNK;
   const int nw = n0 + wave * 32;                        // first key of this wave
@@ -682,33 +748,49 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
   constexpr bool DMA = PIPE && FCSA_DKV_DMA && (BMQ * G::ROWB) % 1024 == 0;
   Stager<T, D, BMQ, NT> sq, sdo;
-  DmaStager<T, D, DMA ? BMQ : 1024, NW> dq_, ddo_;
+  typedef DmaStager<T, D, DMA ? BMQ : 1024, NW> DS;
+  DS dq_, ddo_;
+  typename DS::Stream stq, stdo;      // Q / dO walked tile by tile from the pass's first tile (DMA form)
+  uint32_t q_step = 0, do_step = 0, lds0 = 0;
+  bool far = false;
   if constexpr (DMA) {
     dq_.init(p.q.sn, wave, lane);
     ddo_.init(p.d_out.sn, wave, lane);
+    stq = dq_.open(qbase + (int64_t)t0 * BMQ * p.q.sn, p.q.sn, p.N - t0 * BMQ);
+    stdo = ddo_.open(dobase + (int64_t)t0 * BMQ * p.d_out.sn, p.d_out.sn, p.N - t0 * BMQ);
+    q_step = (uint32_t)(BMQ * p.q.sn);
+    do_step = (uint32_t)(BMQ * p.d_out.sn);
+    far = BMQ * p.q.sn > (int64_t)DS::REBASE || BMQ * p.d_out.sn > (int64_t)DS::REBASE;
+    lds0 = DS::lds_addr(smem);
   } else {
     sq.init(p.q.sn, tid);
     sdo.init(p.d_out.sn, tid);
   }
   float lc_r = 0.f, dl_r = 0.f;
   bool row_ok = false;
-  // loads of tile t; `buf` = the LDS buffer it is going to (the DMA form writes it right away: the caller guarantees that no
-  // wave still reads that buffer)
-  auto load_tile = [&](int t, char* buf) {
-    const int i0 = t * BMQ;
-    if constexpr (DMA) {
-      dq_.issue(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0, buf, wave);
-      ddo_.issue(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0, buf + TILE_B, wave);
-    } else {
-      sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0);
-      sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
-    }
-    if (tid < BMQ) {       // raw loads only: any arithmetic on them here would force an immediate vmcnt wait
+  auto load_rows = [&](int i0) {      // per-query terms of a tile; raw loads only: any arithmetic on them here would force an immediate vmcnt wait
+    if (tid < BMQ) {
       const int i = min(i0 + tid, p.N - 1);
       lc_r = invl_row[i];
       dl_r = delta_row[i];
       row_ok = i0 + tid < p.N;
     }
+  };
+  // Q / dO streams move on to tile t (DMA form): one scalar add each; re-opened when the 32-bit offset would run out
+  auto advance = [&](int t) {
+    stq.off += q_step;
+    stdo.off += do_step;
+    if (far || (stq.off | stdo.off) > DS::REBASE) {
+      stq = dq_.open(qbase + (int64_t)t * BMQ * p.q.sn, p.q.sn, p.N - t * BMQ);
+      stdo = ddo_.open(dobase + (int64_t)t * BMQ * p.d_out.sn, p.d_out.sn, p.N - t * BMQ);
+    }
+  };
+  // loads of tile t through registers (non-DMA form); `buf` = the LDS buffer it is going to
+  auto load_tile = [&](int t, char* buf) {
+    const int i0 = t * BMQ;
+    sq.load(qbase + (int64_t)i0 * p.q.sn, p.q.sn, p.N - i0);
+    sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
+    load_rows(i0);
   };
   auto store_tile = [&](char* buf) {
     if constexpr (DMA) {
@@ -726,7 +808,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     }
   };
 
-  if (t0 < QT) load_tile(t0, smem);
+  if (t0 < QT) {
+    if constexpr (DMA) {
+      dq_.issue(stq, lds0, wave);
+      ddo_.issue(stdo, lds0 + TILE_B, wave);
+      load_rows(t0 * BMQ);
+    } else {
+      load_tile(t0, smem);
+    }
+  }
 
   // K, V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T), kept for the whole loop
   u32x4 kf[G::KS], vf[G::KS];
@@ -781,19 +871,50 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       char* nxt = smem + (par ^ 1) * BUF_B;
       const bool more = t + 1 < QT;
       FCSA_STAMP(ts, 0);
-      if (more) load_tile(t + 1, nxt);
-      FCSA_STAMP(ts, 1);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
+      if constexpr (PIPE && DMA) {
+        // The next tile arrives by LDS-DMA, one piece per wave at a time spread over this tile's blocks
+        if (more) {
+          advance(t + 1);
+          load_rows(i0 + BMQ);
+        }
+        const uint32_t lds_nxt = lds0 + (par ^ 1) * BUF_B;
+        FCSA_STAMP(ts, 1);
+        constexpr int NB = BMQ / 32, NP = 2 * DS::PER;
+        auto share = [&](int ib) {
+          if (more) {
+#pragma unroll
+            for (int k = FCSA_DKV_SPREAD ? ib * NP / NB : (ib == 0 ? 0 : NP); k < (FCSA_DKV_SPREAD ? (ib + 1) * NP / NB : NP); ++k) {
+              if (k < DS::PER) dq_.issue_piece(stq, lds_nxt, k, wave);
+              else ddo_.issue_piece(stdo, lds_nxt + TILE_B, k - DS::PER, wave);
+            }
+          }
+        };
+        bool skip = false;
+        if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
+        if constexpr (!FCSA_DKV_SPREAD) {
+          share(0);
+          if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, [](int) {});
+        } else if (!skip) {
+          dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, share);
+        } else {
+#pragma unroll
+          for (int ib = 0; ib < NB; ++ib) share(ib);
+        }
+      } else {
+      if (more) load_tile(t + 1, nxt);
+      FCSA_STAMP(ts, 1);
       if constexpr (PIPE) {
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
-        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
+        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, [](int) {});
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
         if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
       } else {
         dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
+      }
       }
       FCSA_STAMP(ts, 8);
       if (more) store_tile(nxt);
@@ -803,8 +924,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       if constexpr (!MASKED) ts.close(10);
     }
   };
+  FCSA_PASS_MARK(1);
   run(std::true_type{}, t0, t_m);
+  FCSA_PASS_MARK(2);
   run(std::false_type{}, t_m, QT);
+  FCSA_PASS_MARK(3);
 
   // Epilogue through the LDS (RowEpilogue): every tile ended with a barrier, so no wave still reads the staging buffers.
   {
@@ -827,9 +951,16 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     }
     if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
   }
+  FCSA_PASS_MARK(4);
   }   // pass
+#undef FCSA_PASS_MARK
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (wave & 2) == 0) ts.dump(g_trace_dkv + 32 * ((wave & 1) + 2 * (wave >> 2)), trace_now() - trace_t0);   // waves 0, 1, 4, 5
+  if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (wave & 2) == 0) {      // waves 0, 1, 4, 5
+    unsigned long long* out = g_trace_dkv + 32 * ((wave & 1) + 2 * (wave >> 2));
+    ts.dump(out, trace_now() - trace_t0);
+    for (int ps = 0; ps < 2; ++ps)
+      for (int k = 0; k < 4; ++k) out[14 + 4 * ps + k] = pass_marks[ps][k + 1] - pass_marks[ps][k];   // prologue | masked tiles | unmasked tiles | epilogue
+  }
 #endif
 }
 

@@ -65,6 +65,9 @@ int check_tensor(const char* name, const fcsa_tensor& t, int es, bool required) 
   if (t.stride0 % m || t.stride1 % m || t.stride2 % m)
     return fail(FCSA_ERR_INVALID_ARG, "%s: strides (%lld, %lld, %lld) must keep rows 16-byte aligned", name,
                 (long long)t.stride0, (long long)t.stride1, (long long)t.stride2);
+  // the kernels address the rows of a 256-row tile with 32-bit byte offsets (buffer loads): keep a tile below 1 GiB
+  if (t.stride2 < 0 || t.stride2 * es > (int64_t)(0x3fffffff / 256))
+    return fail(FCSA_ERR_UNSUPPORTED, "%s: row stride %lld elements is negative or above 4 MiB", name, (long long)t.stride2);
   return FCSA_OK;
 }
 

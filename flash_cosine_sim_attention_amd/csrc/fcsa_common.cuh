@@ -337,28 +337,48 @@ template <typename T, int D, int ROWS, int NW> struct DmaStager {
       voff[i] = (int)(row * pitch + (c < G::CPR ? c : 0) * 16);
     }
   }
-  // g: address of (row 0, feature 0) of the tile (wave-uniform); rows >= rows_valid are zero-filled.
   // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write that may alias any later
   // ds_read of the same __shared__ array and drains it (s_waitcnt vmcnt(0)) in front of the next tile's first fragment read,
   // i.e. right after issuing it.  Hidden from the compiler, the transfer overlaps the whole tile; the caller waits for it with
-  // dma_wait() before the barrier that publishes the buffer.  M0 (LDS base of the DMA) is saved and restored around the statement.
-  FCSA_DEV void issue(const char* g, int64_t pitch, int rows_valid, char* tile, int wave) const {
+  // dma_wait() before the barrier that publishes the buffer.
+  // A Stream is the wave-uniform (SGPR) state of one tensor slice that is walked tile by tile: a buffer descriptor of
+  // [g0, g0 + bytes) made ONCE (per pass) and the byte offset of the current tile from g0.  Per tile the kernel only adds the
+  // tile step to `off` (one SALU instruction) -- the scalar unit is shared by all waves of a CU, and rebuilding a descriptor per
+  // tile (64-bit multiplies, range clamp, readfirstlanes: ~35 SALU instructions per tensor, times 8 waves, all right behind the
+  // tile barrier) showed up as ~700 clocks per tile in the dKV phase trace.  Offsets are 32 bit: the kernel re-opens the stream
+  // (rebase) when `off` passes 1 GiB; num_records is clamped to 2 GiB - 1.
+  struct Stream { u32x4 rs; uint32_t off; };
+  static constexpr uint32_t REBASE = 0x3fffffffu;
+  FCSA_DEV Stream open(const char* g, int64_t pitch, int rows_valid) const {
     int64_t bytes = rows_valid > 0 ? (int64_t)(rows_valid - 1) * pitch + ROW_BYTES : 0;
     if (bytes > 0x7fffffff) bytes = 0x7fffffff;
     const uint64_t ga = reinterpret_cast<uint64_t>(g);
-    u32x4 rs;
-    rs[0] = __builtin_amdgcn_readfirstlane((uint32_t)ga);
-    rs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32) & 0xffffu);      // base[47:32], stride 0
-    rs[2] = __builtin_amdgcn_readfirstlane((uint32_t)bytes);                       // num_records
-    rs[3] = 0x00020000u;                                                           // raw buffer, 32-bit data format
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile);   // LDS byte address (low 32 bits of the flat shared address)
+    Stream st;
+    st.rs[0] = __builtin_amdgcn_readfirstlane((uint32_t)ga);
+    st.rs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32) & 0xffffu);      // base[47:32], stride 0
+    st.rs[2] = __builtin_amdgcn_readfirstlane((uint32_t)bytes);                       // num_records
+    st.rs[3] = 0x00020000u;                                                           // raw buffer, 32-bit data format
+    st.off = 0u;
+    return st;
+  }
+  // LDS byte address of a tile (low 32 bits of the flat shared address), wave-uniform
+  static FCSA_DEV uint32_t lds_addr(const char* tile) { return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile); }
+  // piece i of this wave (i < PER) of the tile at st.off -> LDS tile at byte address lds_tile.  The DMA is issued from inline
+  // asm on purpose (see above); M0 (LDS base of the DMA) is saved and restored around the statement.
+  FCSA_DEV void issue_piece(const Stream& st, uint32_t lds_tile, int i, int wave) const {
+    if (NPIECE % NW == 0 || wave + i * NW < NPIECE) {
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(lds_tile + (uint32_t)(wave + i * NW) * 1024u), "v"(voff[i] + st.off), "s"(st.rs) : "memory");
+    }
+  }
+  FCSA_DEV void issue(const Stream& st, uint32_t lds_tile, int wave) const {
 #pragma unroll
-    for (int i = 0; i < PER; ++i)
-      if (NPIECE % NW == 0 || wave + i * NW < NPIECE) {
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(lds0 + (uint32_t)(wave + i * NW) * 1024u), "v"(voff[i]), "s"(rs) : "memory");
-      }
+    for (int i = 0; i < PER; ++i) issue_piece(st, lds_tile, i, wave);
+  }
+  // one-off form: g = address of (row 0, feature 0) of the tile (wave-uniform); rows >= rows_valid are zero-filled
+  FCSA_DEV void issue(const char* g, int64_t pitch, int rows_valid, char* tile, int wave) const {
+    issue(open(g, pitch, rows_valid), lds_addr(tile), wave);
   }
 };
 // all LDS-DMA transfers of this wave have landed (vmcnt also counts the compiler's own loads and stores: conservative)

@@ -345,13 +345,23 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   constexpr bool DMA = FCSA_FWD_DMA && TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
   constexpr bool EARLY = DMA && !DYN;             // (the dynamic-shift pre-pass stages through the same buffers first)
   Stager<T, D, BN, NT> sk, sv;
-  DmaStager<T, D, DMA ? BN : 1024, NW> dk_, dv_;
+  typedef DmaStager<T, D, DMA ? BN : 1024, NW> DS;
+  DS dk_, dv_;
+  typename DS::Stream stk, stv;       // K / V walked tile by tile from key k_lo: one descriptor per pass, one scalar add per tile
+  uint32_t k_step = 0, v_step = 0, lds0 = 0;
+  bool far = false;
   if constexpr (DMA) {
     dk_.init(p.k.sn, wave, lane);
     dv_.init(p.v.sn, wave, lane);
+    stk = dk_.open(kbase, p.k.sn, Mk);
+    stv = dv_.open(vbase, p.v.sn, Mk);
+    k_step = (uint32_t)(BN * p.k.sn);
+    v_step = (uint32_t)(BN * p.v.sn);
+    far = BN * p.k.sn > (int64_t)DS::REBASE || BN * p.v.sn > (int64_t)DS::REBASE;
+    lds0 = DS::lds_addr(smem);
     if (EARLY && nt > 0) {
-      dk_.issue(kbase, p.k.sn, Mk, smem, wave);
-      dv_.issue(vbase, p.v.sn, Mk, smem + TILE_B, wave);
+      dk_.issue(stk, lds0, wave);
+      dv_.issue(stv, lds0 + TILE_B, wave);
     }
   } else {
     sk.init(p.k.sn, tid);
@@ -448,8 +458,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   if (nt > 0) {
     if constexpr (DMA) {
       if (!EARLY) {
-        dk_.issue(kbase, p.k.sn, Mk, smem, wave);
-        dv_.issue(vbase, p.v.sn, Mk, smem + TILE_B, wave);
+        dk_.issue(stk, lds0, wave);
+        dv_.issue(stv, lds0 + TILE_B, wave);
       }
     } else {
       sk.load(kbase, p.k.sn, Mk);
@@ -509,8 +519,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       }
       if constexpr (DMA) {
         if (t + 1 < nt) {
-          dk_.issue(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN), knxt, wave);
-          dv_.issue(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, Mk - (j0 + BN), knxt + TILE_B, wave);
+          stk.off += k_step;
+          stv.off += v_step;
+          if (far || (stk.off | stv.off) > DS::REBASE) {      // 32-bit offsets about to run out: re-open at this tile
+            stk = dk_.open(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN));
+            stv = dv_.open(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, Mk - (j0 + BN));
+          }
+          const uint32_t lds_nxt = lds0 + ((t + 1) & 1) * 2 * TILE_B;
+          dk_.issue(stk, lds_nxt, wave);
+          dv_.issue(stv, lds_nxt + TILE_B, wave);
         }
         FCSA_STAMP(ts, 1);
       } else {

@@ -44,6 +44,17 @@ for r in range(a.rounds + 1):
         _lib.profile_enable(False)
         if r == 0: continue          # first round = warm-up
         for s in st: res[t].setdefault(s["name"], []).append(s["total_ms"] / s["calls"] * 1e3)
+# same inputs through every build: max |difference| of (o, dq, dk, dv) against the first tag (identical math => expect 0)
+outs = {}
+for t in a.tags:
+    _lib._lib = libs[t]
+    assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
+    q.grad = k.grad = v.grad = None
+    o = F.flash_cosine_sim_attention(q, k, v, causal=bool(causal))
+    o.backward(do)
+    outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
+for t in a.tags[1:]:
+    print(f"{t} vs {a.tags[0]}: max|diff| o/dq/dk/dv = " + " ".join(f"{(x - y).abs().max().item():.3g}" for x, y in zip(outs[t], outs[a.tags[0]])))
 names = ["fwd", "bwd_dq", "bwd_dkv", "l2norm"]
 print(f"shape {a.shape} {a.dtype}; median (min) us over {a.rounds} interleaved rounds")
 for t in a.tags:

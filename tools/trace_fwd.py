@@ -23,7 +23,7 @@ names = {"fwd2": ["P1 S0(t) | E1b(t-1) | V0 req, stage store", "P2 PV1(t-1) | E0
          "fwd": ["mask word", "DMA issue (tile t+1)", "-> S0 chain + V requests", "S1 chain x exp(block 0)", "-> barrier entry", "dma wait + barrier", "K requests (tile t+1)", "PV0 x exp(block 1)", "PV1", "loop end"], "dkv": ["issue loads (tile t+1)", "block 0 (incl. exposed first requests)", "ib1 M1: S + dP chains + T requests", "ib1 X: exp / dS / pack", "ib1 M2: dV + dK + R requests", "blocks 2, 3", "-", "-", "stage store", "barrier"], "dq": ["mask word + issue loads (tile t+1)", "tile compute (S, dP, exp, dQ)", "stage store", "barrier"]}.get(which, [f"seg{i}" for i in range(7)])
 for w in range(4):
     a = list(buf[32 * w:32 * w + 32])
-    if which in ("dkv", "fwd"): print("(slot", w, "= wave", (w & 1) + 4 * (w >> 1), ")")
+    if which in ("dkv", "fwd", "dq"): print("(slot", w, "= wave", (w & 1) + 4 * (w >> 1), ")")
     it, total = a[12], a[13]
     if it == 0: print("wave", w, "no iterations"); continue
     seg = a[:len(names)]
@@ -33,3 +33,7 @@ for w in range(4):
     if which == "fwd":
         for ps in range(2):
             print(f"    pass {ps}: Q fragments (+ fused l2norm) {a[14 + 4 * ps]:7d} | first tile visible {a[15 + 4 * ps]:7d} | key loop {a[16 + 4 * ps]:8d} | epilogue {a[17 + 4 * ps]:7d}   ticks;  first iteration of the unmasked loop {a[23 + 2 * ps]:7d}, of the masked loop {a[24 + 2 * ps]:7d}")
+    if which in ("dkv", "dq"):
+        order = "prologue | masked tiles | unmasked tiles | epilogue" if which == "dkv" else "prologue | unmasked tiles | masked tiles | epilogue"
+        for ps in range(2):
+            print(f"    pass {ps}: {order} = " + " | ".join(f"{a[14 + 4 * ps + k_]:7d}" for k_ in range(4)) + "   ticks")
