@@ -50,6 +50,12 @@
 #ifndef FCSA_DQ_DMA
 #define FCSA_DQ_DMA 1          // K / V stages of the dQ kernel by LDS-DMA (16-bit types)
 #endif
+#ifndef FCSA_DKV_AHEAD      // 1: dKV kernel requests the next pass's first tile + K / V fragments from inside the current epilogue
+#define FCSA_DKV_AHEAD 1
+#endif
+#ifndef FCSA_DQ_AHEAD       // 1: dQ kernel requests the next iteration's first stage + row chunks before the current epilogue
+#define FCSA_DQ_AHEAD 1
+#endif
 #ifndef FCSA_DKV_EXP_UNDER_DP    // 1: pipelined dKV tile issues the exponentials of a block between the MFMAs of its dP chain (measured: +1.2 % time)
 #define FCSA_DKV_EXP_UNDER_DP 0
 #endif
@@ -70,6 +76,12 @@ namespace fcsa {
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_dkv[128];
 __device__ unsigned long long g_trace_dq[128];
+#endif
+#ifdef FCSA_TRACE_WG
+__device__ unsigned long long g_trace_wg_dkv[2048];      // per workgroup: [2 * id] = start time, [2 * id + 1] = end time (wave 0)
+__device__ unsigned long long g_trace_wg_dq[2048];
+__device__ unsigned long long g_trace_pass_dq[2560];       // per workgroup (first 256): [pass][5] pass marks of wave 0
+__device__ unsigned long long g_trace_pass_dkv[2560];
 #endif
 
 // =============================================================================================
@@ -118,19 +130,18 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     }
     // (exponentials first, products second: a v_exp_f32 directly followed by the multiply that consumes it costs a hazard nop
     //  plus the transcendental latency, and hipcc schedules the interleaved form that way under register pressure)
-    float pe[16];
+    f32x16 pe;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float x = s[r];               // = c1 * qh.kh + lc already (c1 rides on q, lc is the accumulator's initial value)
       if constexpr (BIAS) x += bv[r];
       pe[r] = fast_exp2(x);
     }
+    if constexpr (MASKED) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float e = pe[r];
-      if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
-      s[r] = e * dp[r];                  // dS; dp already holds dP - delta
+      for (int r = 0; r < 16; ++r) pe[r] = ((w >> crow(r, 0)) & 1u) ? pe[r] : 0.f;
     }
+    mul16(s, pe, dp);                    // dS; dp already holds dP - delta
     if constexpr (BIAS) {                // d_bias += dS: rows owned by this lane alone (see bwd_dq_kernel), 4 consecutive keys per rq
       if (dbias_row != nullptr) {
         if ((p.M & 3) == 0) {            // 16-byte aligned groups (wave-uniform test)
@@ -232,6 +243,19 @@ FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, co
   pp_.tile = next_tile;
 }
 
+// LDS plan of the dQ kernel (EpiLds): the next iteration is requested ahead of the epilogue when the stages arrive by LDS-DMA and
+// the scratch fits behind them.
+template <typename T, int D, int NW, int SUB> struct DqLds
+    : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB,
+             FCSA_DQ_DMA && FCSA_DQ_AHEAD && Traits<T>::ES == 2 && (64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+             ((NW == 8 || D * Traits<T>::ES > FCSA_DQ_2W_BYTES) ? 160 : 80) * 1024> {};
+
+// LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
+template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
+    : EpiLds<T, D, NW, 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4),
+             FCSA_DKV_PIPE && FCSA_DKV_DMA && FCSA_DKV_AHEAD && Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+             ((NW == 8 || D * Traits<T>::ES > FCSA_DKV_2W_BYTES) ? 160 : 80) * 1024> {};
+
 // SUB = 64-key tiles per LDS stage: 1, or 2 in the 8-wave form (one workgroup per CU has the LDS for 128-key stages).  The
 // phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %).
@@ -275,33 +299,25 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
-#ifdef FCSA_TRACE
+#ifdef FCSA_TRACE_WG
   const unsigned long long trace_t0 = trace_now();
+#endif
+#ifdef FCSA_TRACE
   unsigned long long pass_marks[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
 #define FCSA_PASS_MARK(k) pass_marks[pass][k] = trace_now()
+#elif defined(FCSA_TRACE_WG)
+#define FCSA_PASS_MARK(k) do { if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) g_trace_pass_dq[blockIdx.x * 10 + pass * 5 + (k)] = trace_now(); } while (0)
 #else
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
-  for (int red = 0; red < n_red; ++red) {
-  const int b = own_bias ? (p.bias_batch ? owner : red) : owner / p.H;
-  const int h = own_bias ? (p.bias_batch ? red : owner) : owner % p.H;
-  for (int pass = 0; pass < npass; ++pass) {
-  FCSA_PASS_MARK(0);
-  const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
-  const int m0 = mt * BM;
-  const int mw = m0 + wave * 32;
-  const int i = mw + (lane & 31);
-
-  int last_key = Mk - 1;
-  if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
-  const int nt = last_key < 0 ? 0 : last_key / BN + 1;
-
-  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
-  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
   // K / V stages: LDS-DMA for 16-bit types (no staging registers, no ds_write passes; see DmaStager), else through registers.
-  // The first stage is issued HERE, ahead of the Q / dO / O row loads and the delta reduction, so that its latency hides under
-  // them (the previous pass ended with a barrier: the buffers are free).
   constexpr bool DMA = FCSA_DQ_DMA && TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
+  // SEP: the epilogue scratch has its own LDS bytes behind the staging buffers.  Then nothing of one (row tile) iteration has to
+  // be finished before the next one starts loading: the first K / V stage and this lane's Q^ / dO / O row chunks of the NEXT
+  // iteration are requested before the epilogue of the current one and land while it runs (the pass marks of the WG trace showed
+  // 11 % of this kernel in prologues and 7 % in epilogues: exposed round trips, every workgroup of the chip in step).
+  typedef DqLds<T, D, NW, SUB> LDS;
+  constexpr bool SEP = LDS::SEP;
   Stager<T, D, BNS, NT> sk, sv;
   typedef DmaStager<T, D, DMA ? BNS : 1024, NW> DS;
   DS dk_, dv_;
@@ -311,25 +327,95 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   if constexpr (DMA) {
     dk_.init(p.k.sn, wave, lane);
     dv_.init(p.v.sn, wave, lane);
-    stk = dk_.open(kbase, p.k.sn, Mk);
-    stv = dv_.open(vbase, p.v.sn, Mk);
     k_step = (uint32_t)(BNS * p.k.sn);
     v_step = (uint32_t)(BNS * p.v.sn);
     far = BNS * p.k.sn > (int64_t)DS::REBASE || BNS * p.v.sn > (int64_t)DS::REBASE;
     lds0 = DS::lds_addr(smem);
-    if (nt > 0) {
-      dk_.issue(stk, lds0, wave);
-      dv_.issue(stv, lds0 + HALF_B, wave);
-    }
   } else {
     sk.init(p.k.sn, tid);
     sv.init(p.v.sn, tid);
   }
+  // geometry of iteration (pass_): row tile, this lane's row, number of 64-key tiles
+  auto geometry = [&](int pass_, int& m0_, int& nt_) {
+    const int mt_ = p.causal ? (pass_ == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
+    m0_ = mt_ * BM;
+    int last_key = Mk - 1;
+    if (p.causal) last_key = min(last_key, m0_ + BM - 1 + diff);
+    nt_ = last_key < 0 ? 0 : last_key / BN + 1;
+  };
+  // requests of an iteration that need nothing but free staging buffers: first K / V stage (DMA form) and the raw row chunks
+  u32x4 rq_[G::KS], rdo_[G::KS], ro_[G::KS];
+  float rinvl = 1.f;
+  float rinv_n[RowEpilogue<T, D>::NP];
+#pragma unroll
+  for (int e = 0; e < RowEpilogue<T, D>::NP; ++e) rinv_n[e] = 1.f;
+  bool have_pre = false;
+  auto request_ahead = [&](int b_, int h_, int pass_) {
+    int m0_, nt_;
+    geometry(pass_, m0_, nt_);
+    if constexpr (DMA) {
+      stk = dk_.open(p.k.p + (int64_t)b_ * p.k.sb + (int64_t)h_ * p.k.sh + (int64_t)k_lo * p.k.sn, p.k.sn, Mk);
+      stv = dv_.open(p.v.p + (int64_t)b_ * p.v.sb + (int64_t)h_ * p.v.sh + (int64_t)k_lo * p.v.sn, p.v.sn, Mk);
+      if (nt_ > 0) {
+        dk_.issue(stk, lds0, wave);
+        dv_.issue(stv, lds0 + HALF_B, wave);
+      }
+    }
+    if constexpr (!SEP) return;      // (without SEP the rows are loaded where they are used: fewer registers live at once)
+    const int ln = opaque(lane), hi_ = ln >> 5;
+    const int i_ = m0_ + wave * 32 + (ln & 31);
+    const char* qrow = p.q.p + (int64_t)b_ * p.q.sb + (int64_t)h_ * p.q.sh + (int64_t)i_ * p.q.sn;
+    const char* dorow = p.d_out.p + (int64_t)b_ * p.d_out.sb + (int64_t)h_ * p.d_out.sh + (int64_t)i_ * p.d_out.sn;
+    const char* orow = p.o.p + (int64_t)b_ * p.o.sb + (int64_t)h_ * p.o.sh + (int64_t)i_ * p.o.sn;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rq_[kk] = z;
+      rdo_[kk] = z;
+      ro_[kk] = z;
+      if (i_ < p.N) {
+        rq_[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + hi_) * 16);
+        rdo_[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + hi_) * 16);
+        ro_[kk] = *reinterpret_cast<const u32x4*>(orow + (2 * kk + hi_) * 16);
+      }
+    }
+    rinvl = i_ < p.N ? p.inv_l[((int64_t)b_ * p.H + h_) * p.N + i_] : 1.f;
+    // inverse norms of the rows this lane FINISHES in the epilogue (fused l2norm backward): loaded here, carried through the tile
+    // loops (NP registers), so that the epilogue has no global read to wait for
+    const int rows_valid_ = p.N - (m0_ + wave * 32);
+    typedef RowEpilogue<T, D> EP;
+    if (p.rq != nullptr && rows_valid_ > 0)
+      EP::load_inv(rinv_n, p.rq + (((int64_t)b_ * p.H + h_) * p.N + m0_ + wave * 32) * p.G, p.G, p.lgm, ln, rows_valid_);
+  };
+
+  for (int red = 0; red < n_red; ++red) {
+  const int b = own_bias ? (p.bias_batch ? owner : red) : owner / p.H;
+  const int h = own_bias ? (p.bias_batch ? red : owner) : owner % p.H;
+  for (int pass = 0; pass < npass; ++pass) {
+  FCSA_PASS_MARK(0);
+  int m0, nt;
+  geometry(pass, m0, nt);
+  const int mw = m0 + wave * 32;
+  const int i = mw + (lane & 31);
+  const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
+  const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
+  // (the first stage is requested ahead of the row chunks and the delta reduction -- or, with SEP, before the previous epilogue)
+  if (!have_pre) request_ahead(b, h, pass);
 
   // Q, dO fragments (B operands) and delta = <dO_i, O_i>  (replaces backward_preprocess, cu:1256-1335)
   u32x4 qf[G::KS], dof[G::KS];
   float delta = 0.f, lc = 0.f;
-  {
+  float rinv[RowEpilogue<T, D>::NP];
+  if constexpr (SEP) {
+#pragma unroll
+    for (int e = 0; e < RowEpilogue<T, D>::NP; ++e) rinv[e] = rinv_n[e];
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      qf[kk] = p.q_scaled ? rq_[kk] : scale_frag<T>(rq_[kk], p.c1);
+      dof[kk] = rdo_[kk];
+      delta += dot_frag<T>(rdo_[kk], ro_[kk]);
+    }
+  } else {
     const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
     const char* dorow = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh + (int64_t)i * p.d_out.sn;
     const char* orow = p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)i * p.o.sn;
@@ -346,12 +432,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
         delta += dot_frag<T>(dof[kk], of);
       }
     }
-    delta = xhalf_sum(delta);
-    if (i < p.N) {
-      const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
-      lc = __builtin_amdgcn_logf(p.inv_l[ridx]) - p.c2;     // v_log_f32 = log2
-      if (fa.hi == 0 && blockIdx.y == 0) p.delta[ridx] = delta;
-    }
+    rinvl = i < p.N ? p.inv_l[((int64_t)b * p.H + h) * p.N + i] : 1.f;
+  }
+  delta = xhalf_sum(delta);
+  if (i < p.N) {
+    const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
+    lc = __builtin_amdgcn_logf(rinvl) - p.c2;     // v_log_f32 = log2
+    if (fa.hi == 0 && blockIdx.y == 0) p.delta[ridx] = delta;
   }
 
   f32x16 dq[G::DB];
@@ -474,27 +561,49 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   FCSA_PASS_MARK(3);
 
   // Epilogue through the LDS (RowEpilogue): every stage ended with a barrier, so no wave still reads the staging buffers.
+  // With SEP, what the NEXT iteration needs from memory is requested between the epilogue's steps -- after the accumulators went to
+  // the scratch (their registers are free) -- and lands while the epilogue finishes.  The epilogue itself reads nothing from
+  // global memory (inverse norms: loaded with the row chunks; normalised rows: qf, still live), so it never waits for them.
   {
     typedef RowEpilogue<T, D> EP;
-    char* scr = smem + wave * EP::BYTES;
+    char* scr = LDS::scratch(smem, wave);
+    char* xs = LDS::xarea(smem, wave);
     const int rows_valid = p.N - mw;
-    if (rows_valid > 0) {
-      char* dq0 = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)mw * p.dq.sn + (int64_t)blockIdx.y * p.dq_split_stride;
-      if (p.rq != nullptr) {      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
-        const char* x0 = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)mw * p.q.sn;
-        EP::store(scr, dq, p.scale, lane, dq0, p.dq.sn, rows_valid, false, x0, p.q.sn, p.q_scaled ? 1.f / p.c1 : 1.f,
-                  p.rq + (((int64_t)b * p.H + h) * p.N + mw) * p.G, p.G, p.lgm, p.norm_eps);
-      } else {
-        EP::store(scr, dq, p.scale, lane, dq0, p.dq.sn, rows_valid, p.dq_f32 != 0, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);     // cu:1580-1582: dS *= scale
+    const bool fused = p.rq != nullptr;      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
+    const bool xreg = LDS::X && fused;      // (fused implies l2norm_qk, i.e. q_scaled: qf is exactly the stored row c1 * q^)
+    const int le = opaque(lane);
+    if constexpr (!SEP) {      // (with SEP the inverse norms came with the row chunks)
+#pragma unroll
+      for (int e = 0; e < EP::NP; ++e) rinv[e] = 1.f;
+      if (fused && rows_valid > 0) EP::load_inv(rinv, p.rq + (((int64_t)b * p.H + h) * p.N + mw) * p.G, p.G, p.lgm, le, rows_valid);
+    }
+    if (rows_valid > 0) EP::put(scr, dq, p.scale, le, xreg ? qf : nullptr, xs, LDS::XPITCH);                  // cu:1580-1582: dS *= scale
+    have_pre = false;
+    if constexpr (SEP) {
+      const bool next_pass = pass + 1 < npass, next_red = red + 1 < n_red;
+      if (next_pass || next_red) {
+        const int rn = next_pass ? red : red + 1;
+        request_ahead(own_bias ? (p.bias_batch ? owner : rn) : b, own_bias ? (p.bias_batch ? rn : owner) : h, next_pass ? pass + 1 : 0);
+        have_pre = true;
       }
     }
-    if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
+    if (rows_valid > 0) {
+      char* dq0 = p.dq.p + (int64_t)b * p.dq.sb + (int64_t)h * p.dq.sh + (int64_t)mw * p.dq.sn + (int64_t)blockIdx.y * p.dq_split_stride;
+      const char* x0 = fused ? p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)mw * p.q.sn : nullptr;
+      EP::template finish<LDS::X>(scr, xs, LDS::XPITCH, le, dq0, p.dq.sn, rows_valid, fused ? false : p.dq_f32 != 0, x0, p.q.sn, p.q_scaled ? 1.f / p.c1 : 1.f,
+                                  rinv, p.lgm, p.norm_eps);
+    }
+    if constexpr (!SEP) {
+      if (pass + 1 < npass || red + 1 < n_red) __syncthreads();      // the scratch overlaps the staging buffers of the next iteration
+    }
   }
   FCSA_PASS_MARK(4);
   }   // pass
-  if (red + 1 < n_red) __syncthreads();      // next (batch, head): its prologue overwrites the staging buffers
   }   // red
 #undef FCSA_PASS_MARK
+#ifdef FCSA_TRACE_WG
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) { g_trace_wg_dq[2 * blockIdx.x] = trace_t0; g_trace_wg_dq[2 * blockIdx.x + 1] = trace_now(); }
+#endif
 #ifdef FCSA_TRACE
   if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (wave & 2) == 0) {      // waves 0, 1, 4, 5
     unsigned long long* out = g_trace_dq + 32 * ((wave & 1) + 2 * (wave >> 2));
@@ -654,11 +763,11 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
       __builtin_amdgcn_sched_group_barrier(0x400, (16 + G::KS - 1) / G::KS, 0);          // its share of the 16 exponentials
     }
 #endif
+    if constexpr (MASKED) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if constexpr (MASKED) pr[r] = ((w >> crow(r, 0)) & 1u) ? pr[r] : 0.f;
-      s[r] = pr[r] * dp[r];
+      for (int r = 0; r < 16; ++r) pr[r] = ((w >> crow(r, 0)) & 1u) ? pr[r] : 0.f;
     }
+    mul16(s, pr, dp);
     SecondB<T> pb, db_;
     pb.prep(pr);
     db_.prep(s);
@@ -716,37 +825,27 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   const int diff = p.M - p.N;
   Trace ts;
   ts.reset();
-#ifdef FCSA_TRACE
+#ifdef FCSA_TRACE_WG
   const unsigned long long trace_t0 = trace_now();
+#endif
+#ifdef FCSA_TRACE
   unsigned long long pass_marks[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
 #define FCSA_PASS_MARK(k) pass_marks[pass][k] = trace_now()
+#elif defined(FCSA_TRACE_WG)
+#define FCSA_PASS_MARK(k) do { if (tid == 0 && blockIdx.x < 256) g_trace_pass_dkv[blockIdx.x * 10 + pass * 5 + (k)] = trace_now(); } while (0)
 #else
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
-  for (int pass = 0; pass < npass; ++pass) {
-  FCSA_PASS_MARK(0);
-  const int kt = p.causal ? (pass == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
-  const int n0 = kt * BNK;
-  const int nw = n0 + wave * 32;                        // first key of this wave
-  const int j = nw + (lane & 31);                       // this lane's key
-
-  // query tiles this workgroup needs: causal keeps i >= j - diff
+  // (batch, head) is fixed for the workgroup: everything that does not depend on the pass is set up once
   const int QT = (p.N + BMQ - 1) / BMQ;
-  int t0 = 0;
-  if (p.causal) t0 = max(0, n0 - diff) / BMQ;
-
-  // (the first query tile is requested HERE, ahead of the K / V fragment loads, so that its latency hides under them; the
-  //  previous pass ended with a barrier: the buffers are free)
   const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
   const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
-  const char* bias_col = nullptr;                 // column min(j, M-1): always a valid address
-  if constexpr (BIAS)
-    bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
-
   // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
   constexpr bool DMA = PIPE && FCSA_DKV_DMA && (BMQ * G::ROWB) % 1024 == 0;
+  typedef DkvLds<T, D, NW, BMQ, BIAS> LDS;
+  constexpr bool SEP = LDS::SEP;      // see bwd_dq_kernel: the next pass is requested from inside the epilogue of the current one
   Stager<T, D, BMQ, NT> sq, sdo;
   typedef DmaStager<T, D, DMA ? BMQ : 1024, NW> DS;
   DS dq_, ddo_;
@@ -756,8 +855,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   if constexpr (DMA) {
     dq_.init(p.q.sn, wave, lane);
     ddo_.init(p.d_out.sn, wave, lane);
-    stq = dq_.open(qbase + (int64_t)t0 * BMQ * p.q.sn, p.q.sn, p.N - t0 * BMQ);
-    stdo = ddo_.open(dobase + (int64_t)t0 * BMQ * p.d_out.sn, p.d_out.sn, p.N - t0 * BMQ);
     q_step = (uint32_t)(BMQ * p.q.sn);
     do_step = (uint32_t)(BMQ * p.d_out.sn);
     far = BMQ * p.q.sn > (int64_t)DS::REBASE || BMQ * p.d_out.sn > (int64_t)DS::REBASE;
@@ -792,6 +889,65 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     sdo.load(dobase + (int64_t)i0 * p.d_out.sn, p.d_out.sn, p.N - i0);
     load_rows(i0);
   };
+  // geometry of a pass: first key of the workgroup's key tile, first query tile it needs (causal keeps i >= j - diff)
+  auto geometry = [&](int pass_, int& n0_, int& t0_) {
+    const int kt_ = p.causal ? (pass_ == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
+    n0_ = kt_ * BNK;
+    t0_ = p.causal ? max(0, n0_ - diff) / BMQ : 0;
+  };
+  // requests of a pass that need nothing but a free staging buffer 0: first Q / dO tile (DMA form) with its per-query terms, this
+  // lane's K / V fragments, its key-mask byte and the inverse norms its epilogue will use
+  u32x4 rk_[G::KS], rv_[G::KS];
+  uint8_t rmask = 1;
+  float rinv_n[RowEpilogue<T, D>::NP];
+#pragma unroll
+  for (int e = 0; e < RowEpilogue<T, D>::NP; ++e) rinv_n[e] = 1.f;
+  bool have_pre = false;
+  auto request_ahead = [&](int pass_) {
+    int n0_, t0_;
+    geometry(pass_, n0_, t0_);
+    if constexpr (DMA) {
+      stq = dq_.open(qbase + (int64_t)t0_ * BMQ * p.q.sn, p.q.sn, p.N - t0_ * BMQ);
+      stdo = ddo_.open(dobase + (int64_t)t0_ * BMQ * p.d_out.sn, p.d_out.sn, p.N - t0_ * BMQ);
+      if (t0_ < QT) {
+        dq_.issue(stq, lds0, wave);
+        ddo_.issue(stdo, lds0 + TILE_B, wave);
+        load_rows(t0_ * BMQ);
+      }
+    }
+    const int ln = opaque(lane), hi_ = ln >> 5;
+    const int nw_ = n0_ + wave * 32, j_ = nw_ + (ln & 31);
+    const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j_ * p.k.sn;
+    const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j_ * p.v.sn;
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rk_[kk] = z;
+      rv_[kk] = z;
+      if (j_ < p.M) {
+        rk_[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + hi_) * 16);
+        rv_[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + hi_) * 16);
+      }
+    }
+    rmask = (p.mask != nullptr && j_ < p.M) ? p.mask[(int64_t)b * p.M + j_] : (uint8_t)1;
+    typedef RowEpilogue<T, D> EP;
+    if constexpr (SEP) {      // (without SEP the epilogue loads them itself: fewer registers live across the tile loops)
+      if (p.rk != nullptr && p.M - nw_ > 0)
+        EP::load_inv(rinv_n, p.rk + (((int64_t)b * p.H + h) * p.M + nw_) * p.G, p.G, p.lgm, ln, p.M - nw_);
+    }
+  };
+
+  for (int pass = 0; pass < npass; ++pass) {
+  FCSA_PASS_MARK(0);
+  int n0, t0;
+  geometry(pass, n0, t0);
+  const int nw = n0 + wave * 32;                        // first key of this wave
+  const int j = nw + (lane & 31);                       // this lane's key
+  const char* bias_col = nullptr;                 // column min(j, M-1): always a valid address
+  if constexpr (BIAS)
+    bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
+  // (the first query tile is requested ahead of the K / V fragment loads -- or, with SEP, from the previous epilogue)
+  if (!have_pre) request_ahead(pass);
   auto store_tile = [&](char* buf) {
     if constexpr (DMA) {
       dma_wait();
@@ -808,35 +964,23 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     }
   };
 
-  if (t0 < QT) {
-    if constexpr (DMA) {
-      dq_.issue(stq, lds0, wave);
-      ddo_.issue(stdo, lds0 + TILE_B, wave);
-      load_rows(t0 * BMQ);
-    } else {
-      load_tile(t0, smem);
-    }
+  if constexpr (!DMA) {
+    if (t0 < QT) load_tile(t0, smem);
   }
 
   // K, V fragments of this lane's key (B operands of S = Q K^T and dP = dO V^T), kept for the whole loop
   u32x4 kf[G::KS], vf[G::KS];
-  {
-    const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
-    const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j * p.v.sn;
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      kf[kk] = z;
-      vf[kk] = z;
-      if (j < p.M) {
-        kf[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + fa.hi) * 16);
-        if (!p.q_scaled) kf[kk] = scale_frag<T>(kf[kk], p.c1);     // S = Q (c1 K)^T when the Q tile is plain q^
-        vf[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + fa.hi) * 16);
-      }
-    }
+  for (int kk = 0; kk < G::KS; ++kk) {
+    kf[kk] = p.q_scaled ? rk_[kk] : scale_frag<T>(rk_[kk], p.c1);     // S = Q (c1 K)^T when the Q tile is plain q^
+    vf[kk] = rv_[kk];
   }
-  bool key_ok = j < p.M;
-  if (p.mask != nullptr && key_ok) key_ok = p.mask[(int64_t)b * p.M + j] != 0;
+  float rinv[RowEpilogue<T, D>::NP];
+  if constexpr (SEP) {
+#pragma unroll
+    for (int e = 0; e < RowEpilogue<T, D>::NP; ++e) rinv[e] = rinv_n[e];
+  }
+  const bool key_ok = j < p.M && rmask != 0;
   const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
 
@@ -931,29 +1075,48 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   FCSA_PASS_MARK(3);
 
   // Epilogue through the LDS (RowEpilogue): every tile ended with a barrier, so no wave still reads the staging buffers.
+  // With SEP the next pass is requested between its steps and the epilogue reads nothing from global memory (see bwd_dq_kernel).
   {
     typedef RowEpilogue<T, D> EP;
-    char* scr = smem + wave * EP::BYTES;
+    char* scr = LDS::scratch(smem, wave);
+    char* xs = LDS::xarea(smem, wave);
     const int rows_valid = p.M - nw;
+    const bool fused = p.rk != nullptr;      // dk = l2norm_backward(dKh): p.k holds k^ (K/V with heads only), kf = this wave's rows of it
+    const int le = opaque(lane);
+    // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
+    const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
+    if constexpr (!SEP) {
+#pragma unroll
+      for (int e = 0; e < EP::NP; ++e) rinv[e] = 1.f;
+      if (fused && rows_valid > 0) EP::load_inv(rinv, p.rk + (((int64_t)b * p.H + h) * p.M + nw) * p.G, p.G, p.lgm, le, rows_valid);
+    }
+    if (rows_valid > 0) EP::put(scr, dk, kmul, le, (LDS::X && fused) ? kf : nullptr, xs, LDS::XPITCH);
+    have_pre = false;
+    if constexpr (SEP) {
+      if (pass + 1 < npass) {
+        request_ahead(pass + 1);
+        have_pre = true;
+      }
+    }
     if (rows_valid > 0) {
-      // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
-      const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
       char* dk0 = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)nw * p.dk.sn;
       char* dv0 = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)nw * p.dv.sn;
-      if (p.rk != nullptr) {      // dk = l2norm_backward(dKh): p.k holds k^ (K/V with heads only)
-        const char* x0 = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)nw * p.k.sn;
-        EP::store(scr, dk, kmul, lane, dk0, p.dk.sn, rows_valid, false, x0, p.k.sn, 1.f,
-                  p.rk + (((int64_t)b * p.H + h) * p.M + nw) * p.G, p.G, p.lgm, p.norm_eps);
-      } else {
-        EP::store(scr, dk, kmul, lane, dk0, p.dk.sn, rows_valid, p.dk_f32 != 0, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
-      }
-      EP::store(scr, dv, 1.f, lane, dv0, p.dv.sn, rows_valid, p.dv_f32 != 0, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
+      const char* x0 = fused ? p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)nw * p.k.sn : nullptr;
+      EP::template finish<LDS::X>(scr, xs, LDS::XPITCH, le, dk0, p.dk.sn, rows_valid, fused ? false : p.dk_f32 != 0, x0, p.k.sn, 1.f, rinv, p.lgm,
+                                  p.norm_eps);
+      EP::put(scr, dv, 1.f, le, nullptr, xs, LDS::XPITCH);
+      EP::template finish<false>(scr, xs, LDS::XPITCH, le, dv0, p.dv.sn, rows_valid, p.dv_f32 != 0, nullptr, 0, 1.f, rinv, 0, 1.f);
     }
-    if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
+    if constexpr (!SEP) {
+      if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
+    }
   }
   FCSA_PASS_MARK(4);
   }   // pass
 #undef FCSA_PASS_MARK
+#ifdef FCSA_TRACE_WG
+  if (tid == 0 && blockIdx.x < 1024) { g_trace_wg_dkv[2 * blockIdx.x] = trace_t0; g_trace_wg_dkv[2 * blockIdx.x + 1] = trace_now(); }
+#endif
 #ifdef FCSA_TRACE
   if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (wave & 2) == 0) {      // waves 0, 1, 4, 5
     unsigned long long* out = g_trace_dkv + 32 * ((wave & 1) + 2 * (wave >> 2));
@@ -964,6 +1127,22 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
 #endif
 }
 
+#ifdef FCSA_TRACE_WG
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_wg_dq(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_wg_dq), sizeof(unsigned long long) * 2048);
+}
+extern "C" int fcsa_trace_read_pass_dq(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_pass_dq), sizeof(unsigned long long) * 2560);
+}
+extern "C" int fcsa_trace_read_pass_dkv(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_pass_dkv), sizeof(unsigned long long) * 2560);
+}
+extern "C" int fcsa_trace_read_wg_dkv(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_wg_dkv), sizeof(unsigned long long) * 2048);
+}
+namespace fcsa {
+#endif
 #ifdef FCSA_TRACE
 }  // namespace fcsa
 extern "C" int fcsa_trace_read_dq(unsigned long long* out) {
@@ -993,8 +1172,7 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   // 128-key stages (one barrier per 128 keys) in the 8-wave form and, with LDS-DMA staging (no staging registers), also for the
   // one-wave-per-SIMD configurations (16-bit D >= 96: one workgroup per CU, the LDS is there)
   constexpr int SUB = (NW == 8 || (FCSA_DQ_SUB_WIDE && FCSA_DQ_DMA && Traits<T>::ES == 2 && D * Traits<T>::ES > FCSA_DQ_2W_BYTES)) ? 2 : 1;
-  size_t lds = 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K stage + V stage)
-  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
+  const size_t lds = DqLds<T, D, NW, SUB>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
@@ -1024,8 +1202,7 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? FCSA_DKV_BMQ_WIDE : 32) : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
-  size_t lds = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);      // 2 x [Q tile | dO tile | lc | -delta]
-  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
+  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS>::TOTAL;      // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;

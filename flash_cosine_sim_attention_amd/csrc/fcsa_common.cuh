@@ -30,6 +30,7 @@ namespace fcsa {
 
 typedef float    f32x16 __attribute__((ext_vector_type(16)));
 typedef float    f32x4  __attribute__((ext_vector_type(4)));
+typedef float    f32x2  __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2  __attribute__((ext_vector_type(2)));
 typedef short    s16x4  __attribute__((ext_vector_type(4)));
@@ -39,6 +40,9 @@ typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
 
 #define FCSA_DEV __device__ __forceinline__
+#ifndef FCSA_PK_MUL
+#define FCSA_PK_MUL 0      // measured on C3: v_pk_mul_f32 for dS is SLOWER (dq +2.7 %, dkv +1.4 %)
+#endif
 
 // NOTE: always pass vector ELEMENTS through this by-value helper.  `__builtin_bit_cast(float, v[t])`
 // applied directly to an ext_vector element lvalue is miscompiled by hipcc 7.2 (it reads element 0
@@ -103,6 +107,11 @@ template <> struct Traits<F32> {
     return c;
   }
 };
+
+// A value the optimiser must treat as freshly computed here: keeps per-lane address arithmetic of prologues / epilogues from being
+// hoisted out of the pass loop, where it would stay live across the tile loops and push the kernels over their register budget
+// (observed: 10 hoisted address pairs spilled to scratch and reloaded -- a memory round trip each -- in the dQ epilogue).
+FCSA_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // row index (0..31) of accumulator register r for lane half hi
 FCSA_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -367,9 +376,15 @@ template <typename T, int D, int ROWS, int NW> struct DmaStager {
   // asm on purpose (see above); M0 (LDS base of the DMA) is saved and restored around the statement.
   FCSA_DEV void issue_piece(const Stream& st, uint32_t lds_tile, int i, int wave) const {
     if (NPIECE % NW == 0 || wave + i * NW < NPIECE) {
+      // (readfirstlane: no-ops where hipcc already knows the stream state to be wave-uniform; where a merge of two assignments
+      //  made it lose track, they bring the descriptor back into SGPRs, which the instruction requires)
+      u32x4 rs;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rs[e] = __builtin_amdgcn_readfirstlane(st.rs[e]);
+      const uint32_t off = __builtin_amdgcn_readfirstlane(st.off), m0v = __builtin_amdgcn_readfirstlane(lds_tile + (uint32_t)(wave + i * NW) * 1024u);
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "s"(lds_tile + (uint32_t)(wave + i * NW) * 1024u), "v"(voff[i] + st.off), "s"(st.rs) : "memory");
+                   : "=&s"(keep) : "s"(m0v), "v"(voff[i] + off), "s"(rs) : "memory");
     }
   }
   FCSA_DEV void issue(const Stream& st, uint32_t lds_tile, int wave) const {
@@ -500,7 +515,10 @@ template <typename T, int D> struct RowEpilogue {
   static constexpr int RPP = 64 / LPR;                                             // rows per pass
   static constexpr int NP = 32 / RPP;                                              // passes over the 32 rows
   static constexpr int PITCH = D * 4 + 16;                                         // scratch row pitch: +16 keeps the b128 writes conflict free
-  static constexpr int BYTES = 32 * PITCH;                                         // scratch per wave
+  static constexpr int XPITCH = D * TR::ES + 16;                                   // second scratch area: the wave's 32 normalised rows (16-bit types)
+  static constexpr int XBYTES = TR::ES == 2 ? 32 * XPITCH : 0;
+  static constexpr int BYTES_NOX = 32 * PITCH;                                     // scratch per wave without / with the second area
+  static constexpr int BYTES = 32 * PITCH + XBYTES;
 
   // sum over the aligned block of (1 << steps) lanes this lane belongs to (steps <= 4)
   static FCSA_DEV float lane_block_sum(float v, int steps) {
@@ -511,13 +529,35 @@ template <typename T, int D> struct RowEpilogue {
     return v;
   }
 
-  // acc (C layout, lane = row (lane & 31), hi = lane >> 5) * mul  ->  out rows.  rows_valid: rows >= rows_valid are not stored.
+  // The epilogue in three steps, so that a kernel can put the next pass's memory requests between them:
+  //   load_inv  inverse norms of the rows this lane will finish (the only global reads of a fused epilogue with `xf`)
+  //   put       acc (C layout, lane = row (lane & 31), hi = lane >> 5) * mul -> scratch; frees the accumulators
+  //   finish    scratch -> (l2norm backward) -> out rows.  rows_valid: rows >= rows_valid are not stored.
   // xn0 != nullptr: fused l2norm backward against the normalised rows xn0 + row * xn_pitch (element type T, scaled by xn_scale)
   // with inverse norms inv_norm0[row * NG + group]; groups are (8 << lgm) features wide.
-  static FCSA_DEV void store(char* scr, const f32x16 (&acc)[G::DB], float mul, int lane, char* out0, int64_t out_pitch, int rows_valid,
-                             bool out_f32, const char* xn0, int64_t xn_pitch, float xn_scale, const float* inv_norm0, int NG, int lgm,
-                             float eps) {
+  // xf != nullptr (16-bit types, plans with EpiLds::X): the kernel still holds the wave's normalised rows in registers, as the MFMA
+  // operand fragments of its own positions (lane (row, hi) has the 16-byte chunks 2 * kk + hi of its row); they go through the
+  // second scratch area instead of being re-read from global memory.
+  static FCSA_DEV void load_inv(float (&r)[NP], const float* inv_norm0, int NG, int lgm, int lane, int rows_valid) {
+    const int c = lane % LPR, rr = lane / LPR;
+    const int cc = (CH == LPR || c < CH) ? c : 0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      const int row = pp * RPP + rr;
+      const int rowc = row < rows_valid ? row : 0;            // clamped: always a valid address (rows_valid >= 1 here)
+      r[pp] = inv_norm0 != nullptr ? inv_norm0[(int64_t)rowc * NG + (cc >> lgm)] : 1.f;
+    }
+  }
+  // (xs, xpitch): this wave's area for the normalised rows -- behind the f32 scratch (scr + 32 * PITCH, pitch XPITCH) or wherever
+  // the kernel's LDS plan puts it (EpiLds)
+  static FCSA_DEV void put(char* scr, const f32x16 (&acc)[G::DB], float mul, int lane, const u32x4* xf, char* xs, int xpitch) {
     const int x = lane & 31, hi = lane >> 5;
+    if constexpr (TR::ES == 2) {
+      if (xf != nullptr) {
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) *reinterpret_cast<u32x4*>(xs + x * xpitch + (2 * kk + hi) * 16) = xf[kk];
+      }
+    }
 #pragma unroll
     for (int db = 0; db < G::DB; ++db)
 #pragma unroll
@@ -526,7 +566,13 @@ template <typename T, int D> struct RowEpilogue {
           const f32x4 v = {acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul, acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul};
           *reinterpret_cast<f32x4*>(scr + x * PITCH + (32 * db + 8 * rq + 4 * hi) * 4) = v;
         }
-    // (LDS operations of one wave execute in order: the reads below see the writes above)
+  }
+  // (LDS operations of one wave execute in order: the reads here see the writes of put)
+  // XS (compile time): a fused epilogue finds the normalised rows in the scratch (put got `xf`), never in global memory
+  template <bool XS>
+  static FCSA_DEV void finish(const char* scr, const char* xs, int xpitch, int lane, char* out0, int64_t out_pitch, int rows_valid, bool out_f32,
+                              const char* xn0, int64_t xn_pitch, float xn_scale, const float (&rinv)[NP], int lgm, float eps) {
+    constexpr bool x_in_scratch = XS && TR::ES == 2;
     const int c = lane % LPR, rr = lane / LPR;
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
@@ -545,7 +591,7 @@ template <typename T, int D> struct RowEpilogue {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { xh[e] = a[e] * xn_scale; xh[4 + e] = b2[e] * xn_scale; }
         } else {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(xr);
+          const u32x4 a = x_in_scratch ? *reinterpret_cast<const u32x4*>(xs + row * xpitch + cc * 16) : *reinterpret_cast<const u32x4*>(xr);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { xh[2 * e] = TR::lo(a[e]) * xn_scale; xh[2 * e + 1] = TR::hi(a[e]) * xn_scale; }
         }
@@ -554,7 +600,7 @@ template <typename T, int D> struct RowEpilogue {
         for (int e = 0; e < 8; ++e) dot += g[e] * xh[e];
         if (!(CH == LPR || c < CH)) dot = 0.f;                  // padding lanes of a row (D = 96) contribute nothing
         dot = lane_block_sum(dot, lgm);
-        const float r = inv_norm0[(int64_t)rowc * NG + (cc >> lgm)];
+        const float r = rinv[pp];
         const bool clamped = r >= 1.f / eps;
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = clamped ? g[e] * r : r * (g[e] - xh[e] * dot);
@@ -574,6 +620,36 @@ template <typename T, int D> struct RowEpilogue {
       }
     }
   }
+  // all three steps in one call
+  static FCSA_DEV void store(char* scr, const f32x16 (&acc)[G::DB], float mul, int lane, char* out0, int64_t out_pitch, int rows_valid,
+                             bool out_f32, const char* xn0, int64_t xn_pitch, float xn_scale, const float* inv_norm0, int NG, int lgm,
+                             float eps, const u32x4* xf = nullptr) {
+    float rinv[NP];
+    load_inv(rinv, xn0 != nullptr ? inv_norm0 : nullptr, NG, lgm, lane, rows_valid);
+    char* xs = scr + 32 * PITCH;
+    put(scr, acc, mul, lane, xf, xs, XPITCH);
+    if (TR::ES == 2 && xf != nullptr) finish<true>(scr, xs, XPITCH, lane, out0, out_pitch, rows_valid, out_f32, xn0, xn_pitch, xn_scale, rinv, lgm, eps);
+    else finish<false>(scr, xs, XPITCH, lane, out0, out_pitch, rows_valid, out_f32, xn0, xn_pitch, xn_scale, rinv, lgm, eps);
+  }
+};
+
+// LDS plan of a kernel that stages tiles in two buffers (STAGE bytes together) and ends every pass with a RowEpilogue.
+// SEP: the f32 epilogue scratch lies BEHIND the staging buffers instead of in them, so the next pass can start loading (LDS-DMA
+// into staging buffer 0, row fragments into registers) before the epilogue of the current one has run, and no barrier separates
+// the two.  X: there is an area for the normalised rows that come from registers (RowEpilogue::put's `xf`): with SEP it is the
+// SECOND staging buffer (free until the next pass's first loop iteration, which every wave reaches after its epilogue), rows
+// unpadded; without SEP it follows the f32 scratch.  CAP: LDS bytes one workgroup may take (160 KiB when one workgroup per CU is
+// all the registers allow anyway, else half).
+template <typename T, int D, int NW, int STAGE, bool AHEAD_OK, int CAP> struct EpiLds {
+  typedef RowEpilogue<T, D> EP;
+  static constexpr int XROW = D * Traits<T>::ES;
+  static constexpr bool SEP = AHEAD_OK && STAGE + NW * EP::BYTES_NOX <= CAP;
+  static constexpr bool X = Traits<T>::ES == 2 && (SEP ? NW * 32 * XROW <= STAGE / 2 : NW * EP::BYTES <= CAP);
+  static constexpr int PER_WAVE = (X && !SEP) ? EP::BYTES : EP::BYTES_NOX;
+  static constexpr int TOTAL = SEP ? STAGE + NW * PER_WAVE : (STAGE > NW * PER_WAVE ? STAGE : NW * PER_WAVE);
+  static constexpr int XPITCH = SEP ? XROW : EP::XPITCH;
+  static FCSA_DEV char* scratch(char* smem, int wave) { return smem + (SEP ? STAGE : 0) + wave * PER_WAVE; }
+  static FCSA_DEV char* xarea(char* smem, int wave) { return SEP ? smem + STAGE / 2 + wave * 32 * XROW : scratch(smem, wave) + 32 * EP::PITCH; }
 };
 
 // ---- in-kernel phase timing (trace builds only: make EXTRA=-DFCSA_TRACE OUT=../libfcsa_hip_trace.so) ----
@@ -605,11 +681,17 @@ struct Trace {
     out[N + 1] = total;
   }
 };
-FCSA_DEV unsigned long long trace_now() { unsigned long long v; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v)); return v; }
 #define FCSA_STAMP(ts, k) (ts).stamp(k)
 #else
 struct Trace { FCSA_DEV void reset() {} FCSA_DEV void close(int) {} };
 #define FCSA_STAMP(ts, k) ((void)0)
+#endif
+
+#if defined(FCSA_TRACE) && !defined(FCSA_TRACE_WG)
+#define FCSA_TRACE_WG      // the phase-trace build also records every workgroup's start / end time (tools/trace_wg.py)
+#endif
+#ifdef FCSA_TRACE_WG
+FCSA_DEV unsigned long long trace_now() { unsigned long long v; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v)); return v; }
 #endif
 
 // Issue slots of the slot-scheduled kernels (fwd2, dkv2): one MFMA + a fixed share of the VALU work + at most a couple
@@ -619,6 +701,23 @@ struct Trace { FCSA_DEV void reset() {} FCSA_DEV void close(int) {} };
 #define FCSA_SHARE(m, S, N, i) for (int i = (m) * (N) / (S); i < ((m) + 1) * (N) / (S); ++i)
 
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (2^x, quarter rate)
+
+// out[r] = a[r] * b[r] over a 16-register block, two values per instruction (v_pk_mul_f32: packed f32 runs at twice the
+// scalar-f32 rate on CDNA3/4, and every VALU issue slot taken from the partner wave's MFMA stream counts)
+FCSA_DEV void mul16(f32x16& out, const f32x16& a, const f32x16& b) {
+#if FCSA_PK_MUL
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 x = {a[r], a[r + 1]}, y = {b[r], b[r + 1]};
+    const f32x2 z = x * y;
+    out[r] = z[0];
+    out[r + 1] = z[1];
+  }
+#else
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[r] = a[r] * b[r];
+#endif
+}
 
 
 // bit mask (over accumulator-row positions 0..31) of positions <= thr

@@ -45,6 +45,10 @@ namespace fcsa {
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
 #endif
+#ifdef FCSA_TRACE_WG
+__device__ unsigned long long g_trace_wg_fwd[2048];      // per workgroup: [2 * id] = start time, [2 * id + 1] = end time (wave 0)
+__device__ unsigned long long g_trace_pass_fwd[2560];     // per workgroup (first 256): [pass][5] pass marks of wave 0
+#endif
 
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
 template <typename T, bool MASKED, bool BIAS>
@@ -314,13 +318,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
-#ifdef FCSA_TRACE
+#ifdef FCSA_TRACE_WG
   const unsigned long long trace_t0 = trace_now();
 #endif
 #ifdef FCSA_TRACE
   unsigned long long pass_marks[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   unsigned long long first_iter[2][2] = {{0, 0}, {0, 0}};      // duration of the first iteration of the [pass][unmasked, masked] loop
 #define FCSA_PASS_MARK(k) pass_marks[pass][k] = trace_now()
+#elif defined(FCSA_TRACE_WG)
+#define FCSA_PASS_MARK(k) do { if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) g_trace_pass_fwd[blockIdx.x * 10 + pass * 5 + (k)] = trace_now(); } while (0)
 #else
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
@@ -585,12 +591,15 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   {
     typedef RowEpilogue<T, D> EP;
     if (p.N - mw > 0)
-      EP::store(smem + wave * EP::BYTES, o, inv, lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
+      EP::store(smem + wave * EP::BYTES_NOX, o, inv, lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
                 p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     if (pass + 1 < npass) __syncthreads();
   }
   FCSA_PASS_MARK(4);
   }   // pass
+#ifdef FCSA_TRACE_WG
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) { g_trace_wg_fwd[2 * blockIdx.x] = trace_t0; g_trace_wg_fwd[2 * blockIdx.x + 1] = trace_now(); }
+#endif
 #ifdef FCSA_TRACE
   if (blockIdx.x == gridDim.x / 2 + 3 && (tid & 63) == 0 && (NW == 4 ? wave < 4 : (wave & 2) == 0)) {
     unsigned long long* out = g_trace_fwd + 32 * (NW == 4 ? wave : (wave & 1) + 2 * (wave >> 2));
@@ -603,6 +612,16 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 #endif
 }
 
+#ifdef FCSA_TRACE_WG
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_pass_fwd(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_pass_fwd), sizeof(unsigned long long) * 2560);
+}
+extern "C" int fcsa_trace_read_wg_fwd(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_wg_fwd), sizeof(unsigned long long) * 2048);
+}
+namespace fcsa {
+#endif
 #ifdef FCSA_TRACE
 }  // namespace fcsa
 extern "C" int fcsa_trace_read_fwd(unsigned long long* out) {
@@ -988,7 +1007,7 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K tile + V tile) of 64 keys
-  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES) lds = (size_t)NW * RowEpilogue<T, D>::BYTES;   // epilogue scratch reuses the same bytes
+  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES_NOX) lds = (size_t)NW * RowEpilogue<T, D>::BYTES_NOX;   // epilogue scratch reuses the same bytes
   auto kern = fwd_kernel<T, D, NW, BIAS, DYN>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;

@@ -10,7 +10,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 B, H, N, D = 4, 8, 4096, 64
 q, k, v = (torch.randn(B, H, N, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
 do = torch.randn_like(q)
-for _ in range(20):
+for _ in range(int(os.environ.get("ITERS", "20"))):
     q.grad = k.grad = v.grad = None
     F.flash_cosine_sim_attention(q, k, v, causal=True).backward(do)
 torch.cuda.synchronize()
