@@ -91,7 +91,7 @@ template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
                       f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
-                      uint32_t ncm, int i, int j0, int diff, const char* bias_row, float* dbias_row) {
+                      uint32_t ncm, int i, int j0, int diff, const char* bias_row, float* dbias_row, int m_lim) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
@@ -124,7 +124,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     if constexpr (BIAS) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int j = min(jbase + crow(r, 0), p.M - 1);
+        const int j = min(jbase + crow(r, 0), m_lim - 1);      // (key numbering of this workgroup's key range, like j0)
         bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
       }
     }
@@ -148,7 +148,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
             const int j = jbase + 8 * rq;
-            if (j < p.M) {
+            if (j < m_lim) {
               f32x4* g = reinterpret_cast<f32x4*>(dbias_row + j);
               f32x4 a = *g;
 #pragma unroll
@@ -160,7 +160,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int j = jbase + crow(r, 0);
-            if (j < p.M) dbias_row[j] += s[r];
+            if (j < m_lim) dbias_row[j] += s[r];
           }
         }
       }
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   int owner, pt;
   block_to_work(blockIdx.x, own_bias ? (p.bias_batch ? p.B : p.H) : p.B * p.H, PT, owner, pt);
   const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
-  // split-key launches (gridDim.y = p.dq_splits > 1; never causal / bias): this workgroup sees the keys [k_lo, k_lo + Mk) only and
+  // split-key launches (gridDim.y = p.dq_splits > 1; never causal): this workgroup sees the keys [k_lo, k_lo + Mk) only and
   // writes its partial dQ^ (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
   // Like the forward's split (fcsa_fwd.hip), for grids whose row tiles cannot fill the chip.
   int k_lo = 0, Mk = p.M;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
   float* dbias_row = nullptr;                     // only for real rows
   if constexpr (BIAS) {
-    const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M;
+    const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M + k_lo;      // first key of this workgroup's range
     bias_row = p.bias + boff * (int64_t)sizeof(typename TR::elem);
     if (p.d_bias != nullptr && i < p.N) dbias_row = p.d_bias + boff;
   }
@@ -533,9 +533,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
                                               next_here ? t + 1 : -1, t, fa, qf, dof, dq, lc, delta, word, ncm, i, j0, diff, pipe);
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (j0 > mw + 31 + diff);
-        if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row);
+        if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row, Mk);
       } else {
-        dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, dbias_row);
+        dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, dbias_row, Mk);
       }
       FCSA_STAMP(ts, 2);
       if (last_of_stage) {                                 // workgroup-uniform

@@ -134,16 +134,25 @@ struct BwdLayout {
 };
 
 // Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
-// workgroups for 256 CUs), the problem is not causal, has no bias (d_bias ownership) and every split keeps >= 512 keys.
-// Mirrors forward_splits: C4 (1 x 8 heads x 1024 queries, 8192 keys) goes from 64 to 256 workgroups.
-int backward_dq_splits(const fcsa_problem& p) {
+// workgroups for 256 CUs), the problem is not causal and every split keeps >= 512 keys.  Mirrors forward_splits: C4 (1 x 8 heads x
+// 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  `owners`: (batch, head) pairs that get a workgroup per row tile --
+// batch * heads, or with a d_bias request only the bias slices (heads, or batches for a per-batch bias): there a workgroup
+// owns (bias slice, row tile, key range) and loops over the reduced index, so the grid is small exactly when it is slow.
+int dq_splits_for(const fcsa_problem& p, int64_t owners, int min_keys) {
   if (p.causal) return 1;
-  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
+  const int64_t wgs = owners * ((p.q_len + 127) / 128);
   if (wgs <= 0 || wgs >= 128) return 1;
   int64_t s = (256 + wgs - 1) / wgs;
   if (s > 16) s = 16;
-  if (s > p.k_len / 512) s = p.k_len / 512;
+  if (s > p.k_len / min_keys) s = p.k_len / min_keys;
   return s >= 2 ? (int)s : 1;
+}
+int64_t bias_owners(const fcsa_problem& p) { return p.bias_batch_dim ? p.batch : p.heads; }
+// workspace sizing: the larger of the two (the caller may or may not pass d_bias)
+int backward_dq_splits(const fcsa_problem& p) {
+  // (a bias owner runs its key range once per reduced index: shorter ranges still amortise the workgroup's fixed cost)
+  const int a = dq_splits_for(p, (int64_t)p.batch * p.heads, 512), b = dq_splits_for(p, bias_owners(p), 128);
+  return a > b ? a : b;
 }
 
 int log2_blocks_per_group(const fcsa_problem& p) {     // log2(group size / 8), or -1 if not a power of two of 8-blocks
@@ -413,9 +422,11 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.o = view(a->o, es);
   bp.d_out = view(a->d_out, es);
   // split-key dQ needs (batch, head) to be one flat index of the dq output (the finalize kernel sums the partial slabs per
-  // (batch * head) row block) and no bias; otherwise the unsplit kernel runs
+  // (batch * head) row block); otherwise the unsplit kernel runs
   const bool dq_flat = a->dq.stride0 == (int64_t)p.heads * a->dq.stride1;
-  const int dq_splits = (L.dq_splits > 1 && dq_flat && a->attn_bias == nullptr) ? L.dq_splits : 1;
+  const bool own_bias = a->attn_bias != nullptr && a->d_bias != nullptr;
+  const int want_splits = own_bias ? dq_splits_for(p, bias_owners(p), 128) : dq_splits_for(p, (int64_t)p.batch * p.heads, 512);
+  const int dq_splits = (want_splits > 1 && want_splits <= L.dq_splits && dq_flat) ? want_splits : 1;
   const bool dq_slab = dq_splits > 1 || (p.l2norm_qk != 0 && !L.fuse_norm);
   bp.dq_splits = dq_splits;
   bp.dq_split_stride = (int64_t)p.q_len * p.dim_head * 4;

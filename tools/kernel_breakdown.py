@@ -14,6 +14,8 @@ SHAPES = {
     "d32":   dict(q=(4, 8, 4096, 32), kv=(4, 8, 4096, 32), dtype=torch.bfloat16, causal=True, groups=1),
     "d96":   dict(q=(4, 8, 4096, 96), kv=(4, 8, 4096, 96), dtype=torch.bfloat16, causal=True, groups=1),
     "d64f32": dict(q=(2, 8, 2048, 64), kv=(2, 8, 2048, 64), dtype=torch.float32, causal=True, groups=1),
+    "C2bias": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype=torch.float16, causal=False, groups=1, bias=True),
+    "T5bias": dict(q=(8, 12, 512, 64), kv=(8, 12, 512, 64), dtype=torch.bfloat16, causal=False, groups=1, bias=True),
 }
 sel = sys.argv[1:] or list(SHAPES)
 for name in sel:
@@ -22,9 +24,11 @@ for name in sel:
     k = torch.randn(c["kv"], device="cuda", dtype=c["dtype"]).requires_grad_()
     v = torch.randn(c["kv"], device="cuda", dtype=c["dtype"]).requires_grad_()
     do = torch.randn(c["q"], device="cuda", dtype=c["dtype"])
+    bias = torch.randn(c["q"][1], c["q"][2], c["kv"][-2], device="cuda", dtype=c["dtype"]).requires_grad_() if c.get("bias") else None
     def step():
         q.grad = k.grad = v.grad = None
-        F.flash_cosine_sim_attention(q, k, v, causal=c["causal"], groups=c["groups"]).backward(do)
+        if bias is not None: bias.grad = None
+        F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=c["causal"], groups=c["groups"]).backward(do)
     for _ in range(5): step()
     torch.cuda.synchronize()
     _lib.profile_enable(True)
