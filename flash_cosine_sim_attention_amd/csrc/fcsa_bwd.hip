@@ -121,13 +121,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
-    if constexpr (BIAS) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = min(jbase + crow(r, 0), m_lim - 1);      // (key numbering of this workgroup's key range, like j0)
-        bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
-      }
-    }
+    if constexpr (BIAS) load_bias_block<T>(bv, bias_row, jbase, m_lim, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c);      // (key numbering of this workgroup's key range, like j0)
     // (exponentials first, products second: a v_exp_f32 directly followed by the multiply that consumes it costs a hazard nop
     //  plus the transcendental latency, and hipcc schedules the interleaved form that way under register pressure)
     f32x16 pe;

@@ -113,6 +113,36 @@ template <> struct Traits<F32> {
 // (observed: 10 hoisted address pairs spilled to scratch and reloaded -- a memory round trip each -- in the dQ epilogue).
 FCSA_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// Bias values of one 32-key block for the row this lane owns (kernels whose lanes are query rows: forward, dQ): register r <->
+// key jbase + crow(r, 0), i.e. four groups of 4 consecutive keys.  `row` points at key 0 of a valid bias row, keys >= m_lim are
+// clamped (their logits are masked by the caller).  A group that lies inside the row is ONE 8- / 16-byte load when the rows keep
+// that alignment (m % 4 == 0: jbase is a multiple of 4) -- the element-wise form issued 16 two-byte loads per block and lane and
+// made the bias path three times slower than the plain one.
+template <typename T> FCSA_DEV void load_bias_block(float (&bv)[16], const char* row, int jbase, int m_lim, bool rows_aligned, float mul) {
+  typedef typename Traits<T>::elem E;
+  const E* r0 = reinterpret_cast<const E*>(row);
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const int j = jbase + 8 * rq;
+    if (rows_aligned && j + 3 < m_lim) {
+      if constexpr (Traits<T>::ES == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(r0 + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[4 * rq + e] = v[e] * mul;
+      } else {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(r0 + j);
+        bv[4 * rq + 0] = Traits<T>::lo(v[0]) * mul;
+        bv[4 * rq + 1] = Traits<T>::hi(v[0]) * mul;
+        bv[4 * rq + 2] = Traits<T>::lo(v[1]) * mul;
+        bv[4 * rq + 3] = Traits<T>::hi(v[1]) * mul;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[4 * rq + e] = (float)r0[min(j + e, m_lim - 1)] * mul;
+    }
+  }
+}
+
 // row index (0..31) of accumulator register r for lane half hi
 FCSA_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -57,13 +57,9 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
   typedef Traits<T> TR;
   float bv[16];
   if constexpr (BIAS) {
-    // unconditional loads from clamped (always valid) addresses; out-of-range positions are masked below
-    // or never stored, so their value is irrelevant.  bias_row already points at a valid row.
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = min(jbase + crow(r, 0), p.M - 1);
-      bv[r] = (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
-    }
+    // loads from clamped (always valid) addresses; out-of-range positions are masked below or never stored, so their value is
+    // irrelevant.  bias_row already points at a valid row.
+    load_bias_block<T>(bv, bias_row, jbase, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
