@@ -615,11 +615,19 @@ template <typename T, int D, int BMQ, bool MASKED, bool BIAS>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col, Trace& ts) {
+                       const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col, Trace& ts,
+                       BiasBlock<T>& bb, char* bscr, const char* bias_blk, bool bvec, int next_i0, int lane) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
   for (int ib = 0; ib < BMQ / 32; ++ib) {
+    if constexpr (BIAS) {
+      if (bvec) {      // this block's bias values (requested one block ago) -> scratch; request the next block's (see BiasBlock)
+        bb.stage(bscr, lane);
+        const int rown = ib + 1 < BMQ / 32 ? i0 + 32 * (ib + 1) : next_i0;
+        if (rown >= 0) bb.request(bias_blk, min(rown + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
+      }
+    }
     // query i of register r: i0 + 32*ib + crow(r, hi); valid iff i + diff >= j.  Rows >= N carry
     // lc = -inf (P = 0) and zero Q / dO, so whole blocks beyond N contribute exactly nothing.
     // Branch-free and before the MFMA chains on purpose (see fwd_tile).
@@ -645,11 +653,15 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float x = s[r];                 // = c1 * qh.kh + lc already
-      if constexpr (BIAS) {   // clamped row: always a valid address; rows >= N have P = 0 through lc = -inf
-        const int i = min(i0 + 32 * ib + crow(r, 0) + 4 * fa.hi, p.N - 1);
-        const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
-            bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
-        x += (float)bv * p.bias_c;
+      if constexpr (BIAS) {
+        if (bvec) {
+          x += BiasBlock<T>::value(bscr, crow(r, 0) + 4 * fa.hi, lane) * p.bias_c;
+        } else {                // element loads; clamped row: always a valid address; rows >= N have P = 0 through lc = -inf
+          const int i = min(i0 + 32 * ib + crow(r, 0) + 4 * fa.hi, p.N - 1);
+          const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
+              bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
+          x += (float)bv * p.bias_c;
+        }
       }
       float pe = fast_exp2(x);
       if constexpr (MASKED) pe = ((w >> crow(r, 0)) & 1u) ? pe : 0.f;
@@ -938,8 +950,17 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   const int nw = n0 + wave * 32;                        // first key of this wave
   const int j = nw + (lane & 31);                       // this lane's key
   const char* bias_col = nullptr;                 // column min(j, M-1): always a valid address
-  if constexpr (BIAS)
-    bias_col = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem);
+  const char* bias_blk = nullptr;                 // &bias[slice][0][first key of this wave]
+  BiasBlock<T> bb;
+  char* bscr = smem + LDS::TOTAL + wave * BiasBlock<T>::BYTES;      // private scratch of the bias transposition (BIAS launches only)
+  bool bvec = false;                              // whole key tile inside M, rows 16-byte aligned: block loads (BiasBlock)
+  if constexpr (BIAS) {
+    const char* slice = p.bias + (int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
+    bias_col = slice + (int64_t)min(j, p.M - 1) * (int64_t)sizeof(typename TR::elem);
+    bias_blk = slice + (int64_t)nw * (int64_t)sizeof(typename TR::elem);
+    bvec = n0 + BNK <= p.M && ((int64_t)p.M * TR::ES) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    if (bvec && t0 < QT) bb.request(bias_blk, min(t0 * BMQ + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
+  }
   // (the first query tile is requested ahead of the K / V fragment loads -- or, with SEP, from the previous epilogue)
   if (!have_pre) request_ahead(pass);
   auto store_tile = [&](char* buf) {
@@ -1049,9 +1070,16 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
         if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, [](int) {});
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
-        if (!skip) dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
+        const int next_i0 = more ? i0 + BMQ : -1;
+        if (!skip) {
+          dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
+                                          bias_blk, bvec, next_i0, lane);
+        } else if constexpr (BIAS) {      // the block requested for this tile is not used: request the next tile's first block instead
+          if (bvec && more) bb.request(bias_blk, min(next_i0 + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
+        }
       } else {
-        dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts);
+        dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
+                                         bias_blk, bvec, more ? i0 + BMQ : -1, lane);
       }
       }
       FCSA_STAMP(ts, 8);
@@ -1196,7 +1224,8 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? FCSA_DKV_BMQ_WIDE : 32) : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
-  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS>::TOTAL;      // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them
+  // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
+  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;

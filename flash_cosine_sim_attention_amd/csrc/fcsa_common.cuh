@@ -143,6 +143,35 @@ template <typename T> FCSA_DEV void load_bias_block(float (&bv)[16], const char*
   }
 }
 
+// Bias values of one block for kernels whose LANES ARE KEYS (dK/dV): register r of lane (key j, hi) needs bias[query crow(r, hi)][j]
+// -- sixteen different rows, two bytes each.  Loaded that way it is 16 global loads per block and lane (the bias form of the dKV
+// kernel ran 5x slower than the plain one).  Here the wave fetches the [32 queries x 32 keys] block with lanes as QUERY rows
+// (lane (query, hi) takes the 16 keys 16 * hi .. + 15 of its row: 16-byte loads), writes it to a private LDS scratch and reads it
+// back transposed.  The raw loads are issued one block ahead (request), so their latency overlaps a block of work.
+template <typename T> struct BiasBlock {
+  static constexpr int ES = Traits<T>::ES;
+  static constexpr int KB = 32 * ES;                 // bytes of 32 keys
+  static constexpr int PITCH = KB + KB / 4;          // 16 bit: 80, f32: 160 -> the two lane halves (rows 4 apart) hit disjoint banks
+  static constexpr int BYTES = 32 * PITCH;           // scratch per wave
+  static constexpr int NV = KB / 32;                 // 16-byte loads per lane
+  u32x4 raw[NV];
+  // blk = &bias[0][first key of the wave]; row = this lane's (clamped, valid) query row; hi = lane >> 5
+  FCSA_DEV void request(const char* blk, int64_t row, int64_t row_pitch, int hi) {
+    const char* src = blk + row * row_pitch + hi * (KB / 2);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) raw[v] = *reinterpret_cast<const u32x4*>(src + 16 * v);
+  }
+  FCSA_DEV void stage(char* scr, int lane) const {
+    char* dst = scr + (lane & 31) * PITCH + (lane >> 5) * (KB / 2);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<u32x4*>(dst + 16 * v) = raw[v];
+  }
+  // bias[query 32-block row q][this lane's key]
+  static FCSA_DEV float value(const char* scr, int q, int lane) {
+    return (float)*reinterpret_cast<const typename Traits<T>::elem*>(scr + q * PITCH + (lane & 31) * ES);
+  }
+};
+
 // row index (0..31) of accumulator register r for lane half hi
 FCSA_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

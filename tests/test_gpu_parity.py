@@ -184,6 +184,15 @@ GAPS = [
     C._c("x_n1000_d64_causal_f16", h=1, n=1000, d=64, dtype="f16", causal=True, seed=320),
     C._c("x_scale1_d64", n=100, d=64, dtype="bf16", scale=1, seed=321),
     C._c("x_scale16_d64", n=100, d=64, dtype="f16", scale=16, seed=322),
+    # bias rows that keep 8 / 16-byte alignment (M % 8 == 0): block loads in forward / dQ, LDS-transposed blocks in dKV; M = 264
+    # and 132 mix full key tiles (block form) with a partial last one (element form) in one launch; M = 512 on a small grid runs
+    # the key-split d_bias owners
+    C._c("x_bias_vec_m256_d64", b=2, h=3, n=96, m=256, d=64, dtype="f16", bias=True, seed=323),
+    C._c("x_bias_vec_m264_d64_bb", b=3, h=2, n=100, m=264, d=64, dtype="bf16", bias=True, bias_batch=True, seed=324),
+    C._c("x_bias_vec_m132_d32_f32", b=2, h=2, n=70, m=132, d=32, dtype="f32", bias=True, seed=325),
+    C._c("x_bias_vec_causal_n256_d64", b=1, h=2, n=256, d=64, dtype="bf16", causal=True, bias=True, seed=326),
+    C._c("x_bias_vec_m512_d128_splits", b=2, h=2, n=130, m=512, d=128, dtype="f16", bias=True, seed=327),
+    C._c("x_bias_vec_mask_m384_d96", b=2, h=2, n=65, m=384, d=96, dtype="bf16", bias=True, mask=True, seed=328),
 ]
 
 
