@@ -609,6 +609,156 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 }
 
 // =============================================================================================
+// d_bias kernel.  d_bias[slice, i, j] = sum over the OTHER index (batch for a per-head bias, heads for a per-batch bias) of
+// dS[b, h, i, j].  The reference pushes every dS element through an f32 atomic (cu:1574-1576).  Round 2 first made a dQ workgroup
+// own (bias slice, row tile) and add its dS blocks to d_bias with read-modify-writes; that is deterministic but slow (a strided
+// 16-byte read and write per lane and block, and a grid of only slices x row tiles workgroups).  This kernel recomputes S and dP
+// once more for ONE [128 queries x 64 keys] tile of ONE bias slice, runs the reduced index in a loop, keeps the sum in registers
+// and writes the tile once, transposed through the LDS into whole rows: no atomics, no read-modify-write, slices x row tiles x
+// key tiles workgroups, and the dQ kernel runs its plain form.  Needs delta (published by the dQ kernel, launched first).
+// =============================================================================================
+template <typename T, int D>
+__global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_dbias_kernel(const BwdParams p) {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  typedef Traits<T> TR;
+  constexpr int BN = 64, BM = 128, NT = 256;
+  constexpr int TILE_B = BN * G::ROWB;
+  constexpr int OPITCH = 64 * 4 + 16;                                    // output scratch row: 64 f32 + pad
+  extern __shared__ __attribute__((aligned(16))) char smem[];           // K tile | V tile | 4 x [32][OPITCH] output scratch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FragAddr<T, D> fa;
+  fa.init(lane);
+  const int MT = (p.N + BM - 1) / BM;
+  const int owner = blockIdx.x / MT, mt = blockIdx.x % MT;
+  const int j0 = (int)blockIdx.y * BN;                                   // first key of this workgroup's tile
+  const int n_red = p.bias_batch ? p.H : p.B;
+  const int m0 = mt * BM, mw = m0 + wave * 32, i = mw + (lane & 31);
+  const int diff = p.M - p.N;
+  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
+  if (p.causal && j0 > m0 + BM - 1 + diff) {                             // tile entirely above the diagonal: d_bias = 0 (workgroup-uniform)
+    for (int e = tid; e < BM * (BN / 4); e += NT) {
+      const int row = m0 + e / (BN / 4), col = j0 + 4 * (e % (BN / 4));
+      if (row < p.N)
+        for (int c = col; c < min(col + 4, p.M); ++c) p.d_bias[((int64_t)owner * p.N + row) * p.M + c] = 0.f;
+    }
+    return;
+  }
+
+  // bias values of this lane's row for the tile: the same for every reduced index
+  float bv[2][16];
+  {
+    const char* brow = p.bias + (((int64_t)owner * p.N + min(i, p.N - 1)) * (int64_t)p.M + j0) * (int64_t)sizeof(typename TR::elem);
+    const bool aligned = (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) load_bias_block<T>(bv[jb], brow, 32 * jb + 4 * fa.hi, p.M - j0, aligned, p.bias_c);
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jb][r] = 0.f;
+
+  Stager<T, D, BN, NT> sk, sv;
+  sk.init(p.k.sn, tid);
+  sv.init(p.v.sn, tid);
+  for (int red = 0; red < n_red; ++red) {
+    const int b = p.bias_batch ? owner : red, h = p.bias_batch ? red : owner;
+    sk.load(p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j0 * p.k.sn, p.k.sn, p.M - j0);
+    sv.load(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j0 * p.v.sn, p.v.sn, p.M - j0);
+    // this lane's row: Q^ and dO fragments (B operands), log2-normaliser and delta
+    u32x4 qf[G::KS], dof[G::KS];
+    float lc = 0.f, delta = 0.f;
+    {
+      const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+      const char* dorow = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh + (int64_t)i * p.d_out.sn;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        qf[kk] = z;
+        dof[kk] = z;
+        if (i < p.N) {
+          qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+          if (!p.q_scaled) qf[kk] = scale_frag<T>(qf[kk], p.c1);
+          dof[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
+        }
+      }
+      if (i < p.N) {
+        const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
+        lc = __builtin_amdgcn_logf(p.inv_l[ridx]) - p.c2;
+        delta = p.delta[ridx];
+      }
+    }
+    const bool key_ok = (j0 + lane) < p.M && (p.mask == nullptr || p.mask[(int64_t)b * p.M + min(j0 + lane, p.M - 1)] != 0);
+    const uint64_t word = __ballot(key_ok);                               // valid keys of this tile for this batch element
+    __syncthreads();                                                      // the previous iteration's fragment reads are done
+    sk.store(smem, tid);
+    sv.store(smem + TILE_B, tid);
+    __syncthreads();
+    if (p.causal && j0 > mw + 31 + diff) continue;                        // nothing visible for this wave's rows (wave-uniform; barriers already passed)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const uint32_t w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
+      f32x16 sacc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = lc; dp[r] = -delta; }
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) sacc = TR::mfma32(fa.row_frag(smem, 32 * jb, kk), qf[kk], sacc);
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(smem + TILE_B, 32 * jb, kk), dof[kk], dp);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = ((w >> crow(r, 0)) & 1u) ? fast_exp2(sacc[r] + bv[jb][r]) : 0.f;
+        acc[jb][r] += e * dp[r];                                          // dS (cu:1574: before the scale factor)
+      }
+    }
+  }
+
+  // [32 rows x 64 keys] of this wave -> scratch (C layout: lane (row, hi) holds keys 32 * jb + 8 * rq + 4 * hi + 0..3) -> rows
+  __syncthreads();                                                        // (scratch is separate from the tiles, but keep the waves' LDS traffic apart)
+  char* scr = smem + 2 * TILE_B + wave * 32 * OPITCH;
+  {
+    const int x = lane & 31;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 v = {acc[jb][4 * rq], acc[jb][4 * rq + 1], acc[jb][4 * rq + 2], acc[jb][4 * rq + 3]};
+        *reinterpret_cast<f32x4*>(scr + x * OPITCH + (32 * jb + 8 * rq + 4 * fa.hi) * 4) = v;
+      }
+    const bool vec = (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d_bias) & 15) == 0;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      const int row = 4 * pp + (lane >> 4), col = 4 * (lane & 15);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * OPITCH + col * 4);
+      if (mw + row < p.N) {
+        float* o = p.d_bias + ((int64_t)owner * p.N + mw + row) * (int64_t)p.M + j0 + col;
+        if (vec && j0 + col + 3 < p.M) {
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+          for (int c = 0; c < 4; ++c)
+            if (j0 + col + c < p.M) o[c] = v[c];
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int D>
+static hipError_t launch_dbias_t(const BwdParams& p, hipStream_t s) {
+  const int MT = (p.N + 127) / 128, KT = (p.M + 63) / 64;
+  const int64_t owners = p.bias_batch ? p.B : p.H;
+  const size_t lds = 2 * 64 * TileGeom<D, Traits<T>::ES>::ROWB + 4 * 32 * (64 * 4 + 16);
+  auto kern = bwd_dbias_kernel<T, D>;
+  static std::atomic<uint64_t> lds_ok{0};
+  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(owners * MT), (unsigned)KT), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+// =============================================================================================
 // dK / dV kernel
 // =============================================================================================
 template <typename T, int D, int BMQ, bool MASKED, bool BIAS>
@@ -1264,6 +1414,14 @@ template <typename T, int D> static hipError_t launch_dkv_t(const BwdParams& p, 
     default:  return hipErrorInvalidValue;          \
   }
 #endif
+
+hipError_t launch_backward_dbias(int dtype, int D, const BwdParams& p, hipStream_t s) {
+  if (p.B * p.H == 0 || p.N == 0 || p.M == 0 || p.d_bias == nullptr || p.bias == nullptr) return hipSuccess;
+  if (dtype == 2) { FCSA_DISPATCH_D(launch_dbias_t, BF16) }
+  if (dtype == 1) { FCSA_DISPATCH_D(launch_dbias_t, F16) }
+  if (dtype == 0) { FCSA_DISPATCH_D(launch_dbias_t, F32) }
+  return hipErrorInvalidValue;
+}
 
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s) {
   if (p.B * p.H == 0 || p.N == 0) return hipSuccess;

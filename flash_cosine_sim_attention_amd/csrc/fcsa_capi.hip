@@ -138,6 +138,9 @@ struct BwdLayout {
 // 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  `owners`: (batch, head) pairs that get a workgroup per row tile --
 // batch * heads, or with a d_bias request only the bias slices (heads, or batches for a per-batch bias): there a workgroup
 // owns (bias slice, row tile, key range) and loops over the reduced index, so the grid is small exactly when it is slow.
+#ifndef FCSA_DBIAS_KERNEL
+#define FCSA_DBIAS_KERNEL 1
+#endif
 int dq_splits_for(const fcsa_problem& p, int64_t owners, int min_keys) {
   if (p.causal) return 1;
   const int64_t wgs = owners * ((p.q_len + 127) / 128);
@@ -424,7 +427,9 @@ int fcsa_backward(const fcsa_backward_args* a) {
   // split-key dQ needs (batch, head) to be one flat index of the dq output (the finalize kernel sums the partial slabs per
   // (batch * head) row block); otherwise the unsplit kernel runs
   const bool dq_flat = a->dq.stride0 == (int64_t)p.heads * a->dq.stride1;
-  const bool own_bias = a->attn_bias != nullptr && a->d_bias != nullptr;
+  // d_bias: by the dedicated kernel (default), or by dQ workgroups that own a bias slice (FCSA_DBIAS_KERNEL=0 builds, for A/B)
+  const bool want_dbias = a->attn_bias != nullptr && a->d_bias != nullptr;
+  const bool own_bias = want_dbias && !FCSA_DBIAS_KERNEL;
   const int want_splits = own_bias ? dq_splits_for(p, bias_owners(p), 128) : dq_splits_for(p, (int64_t)p.batch * p.heads, 512);
   const int dq_splits = (want_splits > 1 && want_splits <= L.dq_splits && dq_flat) ? want_splits : 1;
   const bool dq_slab = dq_splits > 1 || (p.l2norm_qk != 0 && !L.fuse_norm);
@@ -447,7 +452,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.delta = reinterpret_cast<float*>(ws + L.delta);
   bp.mask = a->mask;
   bp.bias = static_cast<const char*>(a->attn_bias);
-  bp.d_bias = a->d_bias;
+  bp.d_bias = own_bias ? a->d_bias : nullptr;
   bp.B = p.batch; bp.H = p.heads; bp.N = p.q_len; bp.M = p.k_len;
   bp.causal = p.causal; bp.bias_batch = p.bias_batch_dim;
   bp.c1 = p.scale * kLog2e;
@@ -462,6 +467,10 @@ int fcsa_backward(const fcsa_backward_args* a) {
   // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
   if (int rc = timed("bwd_dq", "backward dq", s, [&] { return fcsa::launch_backward_dq(p.dtype, p.dim_head, bp, s); })) return rc;
   if (int rc = timed("bwd_dkv", "backward dkv", s, [&] { return fcsa::launch_backward_dkv(p.dtype, p.dim_head, bp, s); })) return rc;
+  if (want_dbias && !own_bias) {
+    bp.d_bias = a->d_bias;
+    if (int rc = timed("bwd_dbias", "backward d_bias", s, [&] { return fcsa::launch_backward_dbias(p.dtype, p.dim_head, bp, s); })) return rc;
+  }
 
   fcsa::NormBwdParams nb;
   nb.eps = 1e-12f;

@@ -97,6 +97,7 @@ static inline hipError_t ensure_dynamic_lds(K kern, size_t lds, std::atomic<uint
 // dtype: 1 = f16, 2 = bf16 (fcsa_dtype); returns hipError_t of the launch
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s);
+hipError_t launch_backward_dbias(int dtype, int D, const BwdParams& p, hipStream_t s);   // d_bias from recomputed dS tiles (after dq: needs delta)
 hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t s);
 hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s);
 hipError_t launch_l2norm_pair(int dtype, const NormParams& a, const NormParams& b, hipStream_t s);   // q and k in one grid
