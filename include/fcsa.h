@@ -133,10 +133,11 @@ typedef struct fcsa_backward_args {
   fcsa_norm_state norm;          /* from forward (l2norm_qk only) */
   fcsa_tensor     dq;            /* [B,H,N,D]  out */
   fcsa_tensor     dk, dv;        /* [B,Hk,M,D] out */
-  float*          d_bias;        /* [Hb,N,M] float32, ZERO-INITIALISED by the caller, or NULL.  Accumulated with plain,
-                                    deterministic read-modify-writes: each workgroup owns its slice and reduces the
-                                    broadcast index (batch or heads) itself (reference: f32 atomicAdd per element,
-                                    cu:1574-1576; cast at cu:1912) */
+  float*          d_bias;        /* [Hb,N,M] float32 or NULL.  Every element is WRITTEN exactly once, deterministically: the
+                                    d_bias kernel recomputes the dS tiles of a bias slice and sums the broadcast index
+                                    (batch or heads) in registers (reference: f32 atomicAdd per element into a zeroed
+                                    tensor, cu:1574-1576; cast at cu:1912).  Zero-initialising it, as the reference's
+                                    caller does, is harmless and not required. */
   void*           workspace;     /* >= fcsa_backward_workspace_bytes(&p) bytes, 256-byte aligned */
   size_t          workspace_bytes;
   void*           stream;

@@ -14,3 +14,6 @@ echo "== pmc"; bash tools/gpu_pmc.sh > gpurun_out/pmc.log 2>&1; tail -n 3 gpurun
 echo "== configs"; timeout 600 python tools/bench_configs.py > gpurun_out/configs.log 2>&1; tail -n 8 gpurun_out/configs.log | cut -c1-250
 echo "== benchmark.py --causal"; timeout 600 python benchmark.py --causal --dtypes bfloat16,float16 > gpurun_out/benchmark_causal.txt 2>&1; tail -n 9 gpurun_out/benchmark_causal.txt
 echo "== probes"; timeout 120 tools/probes/atomic_probe > gpurun_out/atomic_probe.txt 2>&1; timeout 120 tools/probes/coissue_probe > gpurun_out/coissue_probe.txt 2>&1; tail -n 3 gpurun_out/coissue_probe.txt
+echo "== per-workgroup pass timing (needs the FCSA_TRACE_WG build next to the library)"
+[ -f flash_cosine_sim_attention_amd/libfcsa_hip_wg.so ] && FCSA_LIB="$R/flash_cosine_sim_attention_amd/libfcsa_hip_wg.so" ITERS=3000 timeout 120 python tools/trace_wg.py > gpurun_out/trace_wg.txt 2>&1; grep -v "XCD\|slowest\|fastest" gpurun_out/trace_wg.txt | tail -n 16
+echo "== bias configurations, per kernel"; timeout 100 python tools/kernel_breakdown.py C2bias T5bias > gpurun_out/bias_breakdown.txt 2>&1; tail -n 14 gpurun_out/bias_breakdown.txt
