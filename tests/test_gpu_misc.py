@@ -167,3 +167,33 @@ def test_dbias_is_deterministic_and_matches_autograd():
                                      attn_bias_batch_dim=batch_dim).backward(do.double())
         ref = bias.grad
         assert ((grads[0].double() - ref).norm() / ref.norm()).item() <= 2e-5
+
+
+@pytest.mark.parametrize("l2norm", [False, True])
+def test_wide_row_strides_walk_the_32bit_tile_offsets(l2norm):
+    """q, k, v and dO as views whose rows are 1 MiB apart: the kernels address a streamed tensor with one buffer descriptor per
+    pass and a 32-bit byte offset per tile (DmaStager::Stream), which has to be re-opened once it passes 1 GiB -- with 128-row
+    tiles that happens after 8 tiles here.  Results must be identical to the ones from contiguous copies of the same data."""
+    import flash_cosine_sim_attention_amd as F
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * 2**30:
+        pytest.skip("needs ~9 GiB of device memory for the padded backing tensors")
+    torch.manual_seed(5)
+    n, d, pad = 2304, 64, 524288                                   # row pitch: 524288 bf16 = 1 MiB
+    def wide():
+        backing = torch.empty((1, 1, n, pad), device="cuda", dtype=torch.bfloat16)
+        view = backing[..., :d]
+        view.copy_(torch.randn((1, 1, n, d), device="cuda") * (1.0 if l2norm else 0.35))
+        return view
+    qw, kw, vw, dow = wide(), wide(), wide(), wide()
+    assert qw.stride(2) == pad and not qw.is_contiguous()
+    kwargs = dict(causal=True, l2norm_qk=l2norm, scale=8 if l2norm else 0.125)
+    outs = []
+    for strided in (False, True):
+        q, k, v = ((t if strided else t.contiguous()).detach().requires_grad_() for t in (qw, kw, vw))
+        o = F.flash_cosine_sim_attention(q, k, v, **kwargs)
+        o.backward(dow if strided else dow.contiguous())
+        outs.append([o.detach().float(), q.grad.float(), k.grad.float(), v.grad.float()])
+    for a, b_ in zip(*outs):
+        assert torch.isfinite(b_).all()
+        assert torch.equal(a, b_)
