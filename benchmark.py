@@ -52,6 +52,35 @@ def timed(fn, num_times, backwards, only_backwards):
     return sum(once(True) for _ in range(num_times)) / num_times
 
 
+def graph_replay_ms(fn, zero, backwards, num_times):
+    """mean ms per replay of the window captured in a HIP graph (the library allocates nothing and launches on the caller's
+    stream only, so the op is capturable after a warm-up)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            out = fn()
+            if backwards:
+                out.sum().backward()
+    torch.cuda.current_stream().wait_stream(side)
+    zero()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+        if backwards:
+            out.sum().backward()
+    for _ in range(10):
+        graph.replay()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(num_times):
+        graph.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / num_times
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--causal", default=False, action="store_true")
@@ -62,6 +91,9 @@ def main():
     ap.add_argument("--dtypes", default="float32,float16,bfloat16")
     ap.add_argument("--json", default=None, help="also write the table as JSON to this path")
     ap.add_argument("--seq-lens", type=int, nargs="+", default=list(SEQ_LENS), help="sequence lengths (default: the reference's sweep)")
+    ap.add_argument("--hip-graph", default=False, action="store_true",
+                    help="extra column: the fused op's window captured once in a HIP graph (torch.cuda.graph) and replayed -- what a "
+                         "launch-bound caller (short sequences) gets by capturing its step")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         sys.exit("a GPU must be available to run the benchmark")
@@ -105,6 +137,7 @@ def main():
                 return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=am, is_causal=args.causal)
 
             t_fused = timed(fused, args.num_times, backwards, args.only_backwards)
+            t_graph = graph_replay_ms(fused, zero, backwards, args.num_times) if args.hip_graph and not args.only_backwards else None
             try:
                 t_base = timed(baseline, args.num_times, backwards, args.only_backwards)
             except torch.OutOfMemoryError:
@@ -120,8 +153,8 @@ def main():
             slower = t_fused / t_base if t_base else 0.0
             print(f"seq_len: {seq}\tslower: {slower:.2f}x\tkernel: {t_fused:.3f}ms\tbaseline: "
                   f"{'oom' if t_base is None else '%.3fms' % t_base}\t{tflops:7.1f} TFLOP/s\tsdpa: "
-                  f"{'n/a' if t_sdpa is None else '%.3fms' % t_sdpa}")
-            rows.append(dict(dtype=name, seq_len=seq, kernel_ms=t_fused, baseline_ms=t_base, sdpa_ms=t_sdpa, tflops=tflops))
+                  f"{'n/a' if t_sdpa is None else '%.3fms' % t_sdpa}" + ("" if t_graph is None else f"\thip-graph replay: {t_graph:.3f}ms"))
+            rows.append(dict(dtype=name, seq_len=seq, kernel_ms=t_fused, baseline_ms=t_base, sdpa_ms=t_sdpa, tflops=tflops, graph_ms=t_graph))
             del q, k, v
             torch.cuda.empty_cache()
     if args.json:
