@@ -121,7 +121,9 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
 
     const int jbase = j0 + 32 * jb + 4 * fa.hi;
     float bv[16];
-    if constexpr (BIAS) load_bias_block<T>(bv, bias_row, jbase, m_lim, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c);      // (key numbering of this workgroup's key range, like j0)
+    if constexpr (BIAS)
+      load_bias_block<T>(bv, bias_row, jbase, m_lim, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c,
+                         (p.M & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, fa.hi);      // (key numbering of this workgroup's key range, like j0)
     // (exponentials first, products second: a v_exp_f32 directly followed by the multiply that consumes it costs a hazard nop
     //  plus the transcendental latency, and hipcc schedules the interleaved form that way under register pressure)
     f32x16 pe;
@@ -653,7 +655,8 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
     const char* brow = p.bias + (((int64_t)owner * p.N + min(i, p.N - 1)) * (int64_t)p.M + j0) * (int64_t)sizeof(typename TR::elem);
     const bool aligned = (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) load_bias_block<T>(bv[jb], brow, 32 * jb + 4 * fa.hi, p.M - j0, aligned, p.bias_c);
+    for (int jb = 0; jb < 2; ++jb)
+      load_bias_block<T>(bv[jb], brow, 32 * jb + 4 * fa.hi, p.M - j0, aligned, p.bias_c, aligned && (p.M & 7) == 0, fa.hi);
   }
   f32x16 acc[2];
 #pragma unroll

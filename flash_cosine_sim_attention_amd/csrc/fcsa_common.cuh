@@ -118,9 +118,40 @@ FCSA_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // clamped (their logits are masked by the caller).  A group that lies inside the row is ONE 8- / 16-byte load when the rows keep
 // that alignment (m % 4 == 0: jbase is a multiple of 4) -- the element-wise form issued 16 two-byte loads per block and lane and
 // made the bias path three times slower than the plain one.
-template <typename T> FCSA_DEV void load_bias_block(float (&bv)[16], const char* row, int jbase, int m_lim, bool rows_aligned, float mul) {
+template <typename T> FCSA_DEV void load_bias_block(float (&bv)[16], const char* row, int jbase, int m_lim, bool rows_aligned, float mul,
+                                                    bool rows_aligned8 = false, int hi = 0) {
   typedef typename Traits<T>::elem E;
   const E* r0 = reinterpret_cast<const E*>(row);
+  if constexpr (Traits<T>::ES == 2) {
+    // 16-bit rows that keep 16-byte alignment (m % 8 == 0), whole 32-key block inside the row (wave-uniform test; needs every
+    // lane active): lane (row, hi) fetches the 16 CONSECUTIVE keys 16 * hi .. + 15 of the block as two 16-byte loads -- half the
+    // memory instructions, and 32 instead of 16 useful bytes per row and instruction -- and the lane pair (lane, lane ^ 32)
+    // exchanges the halves it fetched for each other with four v_permlane32_swap (lanes 32..63 of the first register <-> lanes
+    // 0..31 of the second).
+    const int jb = jbase - 4 * hi;
+    if (rows_aligned8 && jb + 31 < m_lim) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(r0 + jb + 16 * hi);
+      const u32x4 a = src[0], b = src[1];
+      uint32_t w[4][2];      // [rq][dword]: keys 8 * rq + 4 * hi + (0, 1 | 2, 3)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const auto sa = __builtin_amdgcn_permlane32_swap(a[d], a[2 + d], false, false);
+        const auto sb = __builtin_amdgcn_permlane32_swap(b[d], b[2 + d], false, false);
+        w[0][d] = sa[0];
+        w[2][d] = sa[1];
+        w[1][d] = sb[0];
+        w[3][d] = sb[1];
+      }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        bv[4 * rq + 0] = Traits<T>::lo(w[rq][0]) * mul;
+        bv[4 * rq + 1] = Traits<T>::hi(w[rq][0]) * mul;
+        bv[4 * rq + 2] = Traits<T>::lo(w[rq][1]) * mul;
+        bv[4 * rq + 3] = Traits<T>::hi(w[rq][1]) * mul;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
     const int j = jbase + 8 * rq;

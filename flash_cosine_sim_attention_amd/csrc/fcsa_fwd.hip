@@ -59,7 +59,8 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
   if constexpr (BIAS) {
     // loads from clamped (always valid) addresses; out-of-range positions are masked below or never stored, so their value is
     // irrelevant.  bias_row already points at a valid row.
-    load_bias_block<T>(bv, bias_row, jbase, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c);
+    load_bias_block<T>(bv, bias_row, jbase, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c,
+                       (p.M & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, (jbase >> 2) & 1);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {

@@ -29,7 +29,7 @@ for name in sel:
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
         F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=c["causal"], groups=c["groups"]).backward(do)
-    for _ in range(5): step()
+    for _ in range(int(os.environ.get("WARM", "5"))): step()
     torch.cuda.synchronize()
     _lib.profile_enable(True)
     for _ in range(10): step()
