@@ -667,39 +667,50 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
   Stager<T, D, BN, NT> sk, sv;
   sk.init(p.k.sn, tid);
   sv.init(p.v.sn, tid);
-  for (int red = 0; red < n_red; ++red) {
-    const int b = p.bias_batch ? owner : red, h = p.bias_batch ? red : owner;
+  // everything an iteration reads from global memory is requested one iteration ahead (its K / V tile into the staging registers,
+  // this lane's row chunks and per-row terms into n*): the round trip overlaps the previous iteration's tile
+  u32x4 nq[G::KS], ndo[G::KS];
+  float ninvl = 1.f, ndelta = 0.f;
+  uint8_t nmask = 1;
+  auto request = [&](int red_) {
+    const int b = p.bias_batch ? owner : red_, h = p.bias_batch ? red_ : owner;
     sk.load(p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j0 * p.k.sn, p.k.sn, p.M - j0);
     sv.load(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j0 * p.v.sn, p.v.sn, p.M - j0);
-    // this lane's row: Q^ and dO fragments (B operands), log2-normaliser and delta
-    u32x4 qf[G::KS], dof[G::KS];
-    float lc = 0.f, delta = 0.f;
-    {
-      const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
-      const char* dorow = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh + (int64_t)i * p.d_out.sn;
+    const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+    const char* dorow = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh + (int64_t)i * p.d_out.sn;
 #pragma unroll
-      for (int kk = 0; kk < G::KS; ++kk) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        qf[kk] = z;
-        dof[kk] = z;
-        if (i < p.N) {
-          qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
-          if (!p.q_scaled) qf[kk] = scale_frag<T>(qf[kk], p.c1);
-          dof[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
-        }
-      }
+    for (int kk = 0; kk < G::KS; ++kk) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      nq[kk] = z;
+      ndo[kk] = z;
       if (i < p.N) {
-        const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
-        lc = __builtin_amdgcn_logf(p.inv_l[ridx]) - p.c2;
-        delta = p.delta[ridx];
+        nq[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+        ndo[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
       }
     }
-    const bool key_ok = (j0 + lane) < p.M && (p.mask == nullptr || p.mask[(int64_t)b * p.M + min(j0 + lane, p.M - 1)] != 0);
-    const uint64_t word = __ballot(key_ok);                               // valid keys of this tile for this batch element
+    if (i < p.N) {
+      const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
+      ninvl = p.inv_l[ridx];
+      ndelta = p.delta[ridx];
+    }
+    nmask = (p.mask != nullptr) ? p.mask[(int64_t)b * p.M + min(j0 + lane, p.M - 1)] : (uint8_t)1;
+  };
+  request(0);
+  for (int red = 0; red < n_red; ++red) {
+    // this lane's row: Q^ and dO fragments (B operands), log2-normaliser and delta
+    u32x4 qf[G::KS], dof[G::KS];
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+      qf[kk] = p.q_scaled ? nq[kk] : scale_frag<T>(nq[kk], p.c1);
+      dof[kk] = ndo[kk];
+    }
+    const float lc = i < p.N ? __builtin_amdgcn_logf(ninvl) - p.c2 : 0.f, delta = i < p.N ? ndelta : 0.f;
+    const uint64_t word = __ballot((j0 + lane) < p.M && nmask != 0);     // valid keys of this tile for this batch element
     __syncthreads();                                                      // the previous iteration's fragment reads are done
     sk.store(smem, tid);
     sv.store(smem + TILE_B, tid);
     __syncthreads();
+    if (red + 1 < n_red) request(red + 1);                                // (the staging registers and n* are free again)
     if (p.causal && j0 > mw + 31 + diff) continue;                        // nothing visible for this wave's rows (wave-uniform; barriers already passed)
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
