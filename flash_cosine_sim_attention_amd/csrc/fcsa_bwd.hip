@@ -53,6 +53,9 @@
 #ifndef FCSA_DKV_AHEAD      // 1: dKV kernel requests the next pass's first tile + K / V fragments from inside the current epilogue
 #define FCSA_DKV_AHEAD 1
 #endif
+#ifndef FCSA_DQ_PIPE_ALL     // 1: the pipelined dQ tile also at two waves per SIMD (A/B builds; measured: no gain)
+#define FCSA_DQ_PIPE_ALL 0
+#endif
 #ifndef FCSA_DQ_AHEAD       // 1: dQ kernel requests the next iteration's first stage + row chunks before the current epilogue
 #define FCSA_DQ_AHEAD 1
 #endif
@@ -521,7 +524,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
         }
       }
       FCSA_STAMP(ts, 1);
-      if constexpr (FCSA_DQ_PIPE && TR::ES == 2 && !BIAS && D * TR::ES > FCSA_DQ_2W_BYTES) {      // one wave per SIMD only
+      if constexpr (FCSA_DQ_PIPE && TR::ES == 2 && !BIAS && (FCSA_DQ_PIPE_ALL || D * TR::ES > FCSA_DQ_2W_BYTES)) {      // one wave per SIMD only
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
