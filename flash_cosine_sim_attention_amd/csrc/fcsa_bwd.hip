@@ -53,6 +53,10 @@
 #ifndef FCSA_DKV_AHEAD      // 1: dKV kernel requests the next pass's first tile + K / V fragments from inside the current epilogue
 #define FCSA_DKV_AHEAD 1
 #endif
+#ifndef FCSA_DQ_SUB8         // 64-key tiles per LDS stage of the 8-wave dQ kernel, 16-bit types: 4 = 256-key stages (one barrier per 256 keys;
+                             // C3: -1.2 % against 128-key stages, although the epilogue scratch then no longer fits behind the stages)
+#define FCSA_DQ_SUB8 4
+#endif
 #ifndef FCSA_DQ_PIPE_ALL     // 1: the pipelined dQ tile also at two waves per SIMD (A/B builds; measured: no gain)
 #define FCSA_DQ_PIPE_ALL 0
 #endif
@@ -255,9 +259,9 @@ template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
              FCSA_DKV_PIPE && FCSA_DKV_DMA && FCSA_DKV_AHEAD && Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
              ((NW == 8 || D * Traits<T>::ES > FCSA_DKV_2W_BYTES) ? 160 : 80) * 1024> {};
 
-// SUB = 64-key tiles per LDS stage: 1, or 2 in the 8-wave form (one workgroup per CU has the LDS for 128-key stages).  The
-// phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
-// halves that (the same change gave the dKV kernel 4.5 %).
+// SUB = 64-key tiles per LDS stage: 1, or 2 / 4 in the 8-wave form (one workgroup per CU has the LDS for 128- / 256-key stages).
+// The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
+// halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
 template <typename T, int D, int NW, bool BIAS, int SUB>
 __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
@@ -1360,7 +1364,9 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   // 128-key stages (one barrier per 128 keys) in the 8-wave form and, with LDS-DMA staging (no staging registers), also for the
   // one-wave-per-SIMD configurations (16-bit D >= 96: one workgroup per CU, the LDS is there)
-  constexpr int SUB = (NW == 8 || (FCSA_DQ_SUB_WIDE && FCSA_DQ_DMA && Traits<T>::ES == 2 && D * Traits<T>::ES > FCSA_DQ_2W_BYTES)) ? 2 : 1;
+  // 8-wave form: 256-key stages where they arrive by LDS-DMA (no staging registers), 128-key stages through registers (f32)
+  constexpr int SUB = NW == 8 ? ((FCSA_DQ_DMA && Traits<T>::ES == 2) ? FCSA_DQ_SUB8 : 2)
+                              : (FCSA_DQ_SUB_WIDE && FCSA_DQ_DMA && Traits<T>::ES == 2 && D * Traits<T>::ES > FCSA_DQ_2W_BYTES) ? 2 : 1;
   const size_t lds = DqLds<T, D, NW, SUB>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
   static std::atomic<uint64_t> lds_ok{0};
