@@ -281,9 +281,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   // d_bias[h or b, i, j] = sum over the OTHER index (batch for a per-head bias, heads for a per-batch bias) of dS[b, h, i, j].
-  // The reference pushes every dS element through an f32 atomic (cu:1574-1576).  Here a workgroup OWNS (bias slice, row tile):
-  // it runs the reduced index sequentially (`red` loop) and adds each dS block to d_bias with plain read-modify-writes of rows
-  // only this wave ever touches -- deterministic, no atomics.  Without a d_bias request: one (batch, head) per workgroup.
+  // The product path computes it in bwd_dbias_kernel (below) and calls this kernel with p.d_bias == nullptr.  The in-kernel form
+  // is kept for A/B builds (FCSA_DBIAS_KERNEL=0 in fcsa_capi.hip): a workgroup OWNS (bias slice, row tile[, key range]), runs the
+  // reduced index sequentially (`red` loop) and adds each dS block to d_bias with plain read-modify-writes of rows only this wave
+  // ever touches -- deterministic, no atomics, but 2x slower at C2.  Without a d_bias pointer: one (batch, head) per workgroup.
   const bool own_bias = BIAS && p.d_bias != nullptr;
   const int n_red = own_bias ? (p.bias_batch ? p.H : p.B) : 1;
   int owner, pt;
