@@ -40,6 +40,11 @@
 #ifndef FCSA_FWD_QPRE        // 1: the second pass's raw q rows are requested before the first pass's epilogue (measured: +0.7 % time)
 #define FCSA_FWD_QPRE 0
 #endif
+#ifndef FCSA_FWD_SUB         // 64-key tiles per LDS stage of the forward kernel where the stages arrive by LDS-DMA.  2 (one barrier per 128
+                             // keys, as in the backward kernels) measured +1.8 % time at C3: the forward's barrier sits in the MIDDLE of a tile
+                             // (mid()), where the old wave of a SIMD waits less than at a tile end; 1 it stays
+#define FCSA_FWD_SUB 1
+#endif
 #ifndef FCSA_FWD_DMA
 #define FCSA_FWD_DMA 1         // K / V tiles of the 32-rows-per-wave forward kernel by LDS-DMA (16-bit types)
 #endif
@@ -294,6 +299,12 @@ FCSA_DEV void load_q_frags(const FwdParams& p, int b, int h, int i, const FragAd
   finish_q_frags<T, D>(p, b, h, i, fa, qf);
 }
 
+// 64-key tiles per LDS stage of fwd_kernel (kernel and launcher must agree): FCSA_FWD_SUB with LDS-DMA staging and no dynamic-shift
+// pre-pass (which stages single tiles through the same buffers), else 1
+template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
+  return (FCSA_FWD_DMA && !DYN && Traits<T>::ES == 2 && (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0) ? FCSA_FWD_SUB : 1;
+}
+
 // DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
 // the main loop then starts the S accumulators from -max instead of the static shift; inv_l is saved for shift 0.
 template <typename T, int D, int NW, bool BIAS, bool DYN>
@@ -302,7 +313,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BN * G::ROWB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+  constexpr int SUB = fwd_stage_tiles<T, D, DYN>();       // 64-key tiles per stage
+  constexpr int STAGE_B = 2 * SUB * TILE_B;                // K tiles | V tiles of one stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][SUB K tiles | SUB V tiles]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -366,7 +379,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   constexpr bool DMA = FCSA_FWD_DMA && TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
   constexpr bool EARLY = DMA && !DYN;             // (the dynamic-shift pre-pass stages through the same buffers first)
   Stager<T, D, BN, NT> sk, sv;
-  typedef DmaStager<T, D, DMA ? BN : 1024, NW> DS;
+  typedef DmaStager<T, D, DMA ? BN * SUB : 1024, NW> DS;
   DS dk_, dv_;
   typename DS::Stream stk, stv;       // K / V walked tile by tile from key k_lo: one descriptor per pass, one scalar add per tile
   uint32_t k_step = 0, v_step = 0, lds0 = 0;
@@ -376,13 +389,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     dv_.init(p.v.sn, wave, lane);
     stk = dk_.open(kbase, p.k.sn, Mk);
     stv = dv_.open(vbase, p.v.sn, Mk);
-    k_step = (uint32_t)(BN * p.k.sn);
-    v_step = (uint32_t)(BN * p.v.sn);
-    far = BN * p.k.sn > (int64_t)DS::REBASE || BN * p.v.sn > (int64_t)DS::REBASE;
+    k_step = (uint32_t)(BN * SUB * p.k.sn);
+    v_step = (uint32_t)(BN * SUB * p.v.sn);
+    far = BN * SUB * p.k.sn > (int64_t)DS::REBASE || BN * SUB * p.v.sn > (int64_t)DS::REBASE;
     lds0 = DS::lds_addr(smem);
     if (EARLY && nt > 0) {
       dk_.issue(stk, lds0, wave);
-      dv_.issue(stv, lds0 + TILE_B, wave);
+      dv_.issue(stv, lds0 + SUB * TILE_B, wave);
     }
   } else {
     sk.init(p.k.sn, tid);
@@ -486,7 +499,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     if constexpr (DMA) {
       if (!EARLY) {
         dk_.issue(stk, lds0, wave);
-        dv_.issue(stv, lds0 + TILE_B, wave);
+        dv_.issue(stv, lds0 + SUB * TILE_B, wave);
       }
     } else {
       sk.load(kbase, p.k.sn, Mk);
@@ -532,8 +545,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       if (t == t_begin) first_iter[pass][MASKED ? 1 : 0] = trace_now();
 #endif
       const int j0 = t * BN;
-      const char* vcur = smem + (t & 1) * 2 * TILE_B + TILE_B;
-      char* knxt = smem + ((t + 1) & 1) * 2 * TILE_B;
+      const int u = t / SUB, sub = t % SUB;                    // stage, tile inside the stage
+      const char* vcur = smem + (u & 1) * STAGE_B + (SUB + sub) * TILE_B;
+      char* knxt = smem + (sub + 1 < SUB ? (u & 1) * STAGE_B + (sub + 1) * TILE_B : ((u + 1) & 1) * STAGE_B);
+      const bool last_of_stage = sub == SUB - 1 || t + 1 >= nt;   // workgroup-uniform
       FCSA_STAMP(ts, 0);
       uint64_t word = 0;
       if constexpr (MASKED) {
@@ -545,16 +560,17 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
         }
       }
       if constexpr (DMA) {
-        if (t + 1 < nt) {
+        // stage u + 1 is requested at the first tile of stage u: its buffer was last read in stage u - 1, which ended with a barrier
+        if (sub == 0 && (u + 1) * SUB < nt) {
           stk.off += k_step;
           stv.off += v_step;
-          if (far || (stk.off | stv.off) > DS::REBASE) {      // 32-bit offsets about to run out: re-open at this tile
-            stk = dk_.open(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN));
-            stv = dv_.open(vbase + (int64_t)(j0 + BN) * p.v.sn, p.v.sn, Mk - (j0 + BN));
+          if (far || (stk.off | stv.off) > DS::REBASE) {      // 32-bit offsets about to run out: re-open at this stage
+            stk = dk_.open(kbase + (int64_t)(u + 1) * BN * SUB * p.k.sn, p.k.sn, Mk - (u + 1) * BN * SUB);
+            stv = dv_.open(vbase + (int64_t)(u + 1) * BN * SUB * p.v.sn, p.v.sn, Mk - (u + 1) * BN * SUB);
           }
-          const uint32_t lds_nxt = lds0 + ((t + 1) & 1) * 2 * TILE_B;
+          const uint32_t lds_nxt = lds0 + ((u + 1) & 1) * STAGE_B;
           dk_.issue(stk, lds_nxt, wave);
-          dv_.issue(stv, lds_nxt + TILE_B, wave);
+          dv_.issue(stv, lds_nxt + SUB * TILE_B, wave);
         }
         FCSA_STAMP(ts, 1);
       } else {
@@ -569,15 +585,17 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
         }
       }
       FCSA_STAMP(ts, 2);
-      auto mid = [&]() {          // every LDS read of this tile has been issued; publish tile t+1
+      auto mid = [&]() {          // every LDS read of this tile has been issued; at the last tile of a stage: publish the next stage
         FCSA_STAMP(ts, 5);
-        if constexpr (DMA) dma_wait();
-        __syncthreads();
+        if (last_of_stage) {
+          if constexpr (DMA) dma_wait();
+          __syncthreads();
+        }
         FCSA_STAMP(ts, 6);
       };
       bool skip = false;
       if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
-      if (!PREFETCH_K && !skip) request_k(vcur - TILE_B);
+      if (!PREFETCH_K && !skip) request_k(vcur - SUB * TILE_B);
       if (skip) {
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
@@ -1033,7 +1051,7 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  size_t lds = 4 * 64 * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K tile + V tile) of 64 keys
+  size_t lds = 4 * 64 * fwd_stage_tiles<T, D, DYN>() * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K + V tiles of a stage)
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES_NOX) lds = (size_t)NW * RowEpilogue<T, D>::BYTES_NOX;   // epilogue scratch reuses the same bytes
   auto kern = fwd_kernel<T, D, NW, BIAS, DYN>;
   static std::atomic<uint64_t> lds_ok{0};
