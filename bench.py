@@ -62,6 +62,130 @@ def aggregate_over_ranks(elapsed_s, flops_local, dist=None, device="cpu"):
     return float(t.item()), float(f.item())
 
 
+# ---- the other BASELINE configs and the reference's own timing protocol, in the SAME driver-run line (rank 0) -------------
+# Shapes / flags are BASELINE.json `configs` (C2, C4, C5) plus C5 at scale 8 (the table's default scale; runs the
+# dynamic-shift forward), C3 at D = 128 and a learned-bias case.  Protocol = the reference's benchmark.py:7-56: 10 warm-up
+# calls, then the mean of 20 device-event timed calls; the forward+backward window is `fn(); out.backward(dO)` like the
+# headline step.  Each entry also times torch SDPA (softmax flash attention) on the same tensors.
+EXTRA_CONFIGS = {
+    "C2": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype="f16", causal=False, mask=False, scale=8, groups=1, bwd=False),
+    "C4": dict(q=(1, 8, 1024, 64), kv=(1, 8, 8192, 64), dtype="f16", causal=False, mask=True, scale=8, groups=1, bwd=True),
+    "C5": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype="bf16", causal=True, mask=False, scale=1, groups=8, bwd=True),
+    "C5s8": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype="bf16", causal=True, mask=False, scale=8, groups=8, bwd=True),
+    "C3_d128": dict(q=(4, 8, 4096, 128), kv=(4, 8, 4096, 128), dtype="bf16", causal=True, mask=False, scale=8, groups=1, bwd=True),
+    "C2_bias": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype="f16", causal=False, mask=False, scale=8, groups=1, bwd=True, bias=True),
+}
+_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def event_time_ms(fn, iters=20, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def run_extra_config(F, c, sdpa=True):
+    dt = _DT[c["dtype"]]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, H, N, D = c["q"]
+    M = c["kv"][-2]
+    q = torch.randn(c["q"], device="cuda", dtype=dt, generator=g).requires_grad_(c["bwd"])
+    k = torch.randn(c["kv"], device="cuda", dtype=dt, generator=g).requires_grad_(c["bwd"])
+    v = torch.randn(c["kv"], device="cuda", dtype=dt, generator=g).requires_grad_(c["bwd"])
+    mask = (torch.rand((B, M), device="cuda", generator=g) > 0.25) if c["mask"] else None      # README protocol: 25 % masked
+    do = torch.randn(c["q"], device="cuda", dtype=dt, generator=g)
+    bias = (0.5 * torch.randn((H, N, M), device="cuda", dtype=dt, generator=g)).requires_grad_() if c.get("bias") else None
+    unit = B * H * N * M * D * (causal_fraction(N, M) if c["causal"] else 1.0)
+    kw = dict(mask=mask, attn_bias=bias, causal=c["causal"], scale=c["scale"], groups=c["groups"])
+
+    def fwd():
+        with torch.no_grad():
+            return F.flash_cosine_sim_attention(q, k, v, **kw)
+
+    def fb():
+        q.grad = k.grad = v.grad = None
+        if bias is not None:
+            bias.grad = None
+        F.flash_cosine_sim_attention(q, k, v, **kw).backward(do)
+
+    r = {}
+    t_f = event_time_ms(fwd)
+    r["fwd_ms"] = round(t_f, 4)
+    r["fwd_tflops"] = round(4 * unit / t_f / 1e9, 1)
+    if c["bwd"]:
+        t_fb = event_time_ms(fb)
+        r["ms"] = round(t_fb, 4)
+        r["tflops"] = round(14 * unit / t_fb / 1e9, 1)
+    else:
+        r["ms"], r["tflops"] = r["fwd_ms"], r["fwd_tflops"]
+    if sdpa:
+        try:
+            ke, ve = (k, v) if k.dim() == 4 else (k[:, None].expand(B, H, M, D), v[:, None].expand(B, H, M, D))
+            am = None if mask is None else mask[:, None, None, :].expand(B, 1, N, M)
+            if bias is not None:
+                am = bias.detach()[None].expand(B, H, N, M)                  # additive float mask (SDPA gives no bias gradient)
+            sd = torch.nn.functional.scaled_dot_product_attention
+
+            def sfwd():
+                with torch.no_grad():
+                    return sd(q, ke, ve, attn_mask=am, is_causal=c["causal"])
+
+            def sfb():
+                q.grad = k.grad = v.grad = None
+                sd(q, ke, ve, attn_mask=am, is_causal=c["causal"]).backward(do)
+
+            ts = event_time_ms(sfb if c["bwd"] else sfwd)
+            r["sdpa_ms"] = round(ts, 4)
+            r["vs_flash_sdpa"] = round(ts / r["ms"], 2)
+        except Exception as ex:                                   # pragma: no cover
+            r["sdpa_error"] = repr(ex)[:120]
+    return r
+
+
+def reference_protocol(F, w, dt):
+    """The reference's timing protocol on the headline workload (flash_cosine_sim_attention/benchmark.py:7-56, 46-48):
+    10 warm-ups, mean of 20 calls, each timed by its own device-event pair around `out = fn(); out.sum().backward()`."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    shp = (w["B"], w["H"], w["N"], w["D"])
+    q, k, v = (torch.randn(shp, device="cuda", dtype=dt, generator=g).requires_grad_() for _ in range(3))
+
+    def once():
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        q.grad = k.grad = v.grad = None
+        s.record()
+        out = F.flash_cosine_sim_attention(q, k, v, causal=w["causal"], scale=w["scale"], groups=w["groups"])
+        out.sum().backward()
+        e.record()
+        return s, e
+
+    for _ in range(10):
+        once()
+    torch.cuda.synchronize()
+    ev = [once() for _ in range(20)]
+    torch.cuda.synchronize()
+    ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+    return {"ms": round(ms, 4), "tflops": round(flops(w) / ms / 1e9, 1),
+            "what": "reference protocol: 10 warm-ups, mean of 20 event-timed `out = fn(); out.sum().backward()` (includes the .sum() "
+                    "kernel and the ones-expand of its backward)"}
+
+
+def small_n(F):
+    """host-bound sizes: f16 causal forward+backward, B4 H8 D64, N = 128 / 256 / 512, eager, against SDPA (reference protocol)."""
+    out = {}
+    for n in (128, 256, 512):
+        c = dict(q=(4, 8, n, 64), kv=(4, 8, n, 64), dtype="f16", causal=True, mask=False, scale=8, groups=1, bwd=True)
+        r = run_extra_config(F, c)
+        out[str(n)] = {"ms": r["ms"], "sdpa_ms": r.get("sdpa_ms"), "vs_flash_sdpa": r.get("vs_flash_sdpa")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +194,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)     # reference protocol: 10 warm-ups (benchmark.py:11)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the instrumented pass for the roofline object")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the C2 / C4 / C5 / ... entries and the reference-protocol leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,16 +284,20 @@ def main():
             # committed measurement of this same command (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE x2
             # gfx950 correction) -- but ONLY if it was taken on the very library binary that is loaded now (sha256 recorded by
             # the PMC run); after any kernel change it reads null until the PMC passes are repeated.
-            tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(tfile):
+            import glob
+            sha, hit = lib_sha256(), None
+            for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
                 rec = json.load(open(tfile))
                 tk = rec.get("kernels", {}).get(dom["name"] + "_kernel")
-                if tk and rec.get("lib_sha256") == lib_sha256():
-                    roofline["traffic"] = round(tk["total_bytes"])
-                    roofline["traffic_source"] = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; "
-                                                  "same libfcsa_hip.so sha256 %s)" % rec["lib_sha256"][:12])
-                else:
-                    roofline["traffic_source"] = "null: profiles/r02_pmc_traffic.json was measured on a different build of libfcsa_hip.so"
+                if tk and rec.get("lib_sha256") == sha:
+                    hit = (os.path.relpath(tfile, ROOT), tk)
+                    break
+            if hit:
+                roofline["traffic"] = round(hit[1]["total_bytes"])
+                roofline["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; same libfcsa_hip.so sha256 %s)"
+                                              % (hit[0], sha[:12]))
+            else:
+                roofline["traffic_source"] = "null: no profiles/r*_pmc_traffic.json was measured on this build of libfcsa_hip.so (sha256 %s)" % sha[:12]
 
     # ---- stock softmax flash attention on the same box, shape, dtype, causal flag (the ">= 1.2x" target) -------
     sdpa = None
@@ -208,6 +337,18 @@ def main():
                 md = max(md, (o[b, h].float() - ref).abs().max().item())
             max_delta = md
 
+    # ---- the other configs, the reference's timing protocol, host-bound sizes (rank 0; ~2 s) -----------------------------
+    configs = ref_proto = small = None
+    if rank == 0 and not args.no_extra_configs:
+        configs = {}
+        for name, c in EXTRA_CONFIGS.items():
+            try:
+                configs[name] = run_extra_config(F, c)
+            except Exception as ex:                                # pragma: no cover
+                configs[name] = {"error": repr(ex)[:200]}
+        ref_proto = reference_protocol(F, w, dt)
+        small = small_n(F)
+
     # ---- CPU baseline: ports of the reference's CPU-runnable paths on the host cores, bounded samples ----------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -244,6 +385,9 @@ def main():
             "flash_sdpa": sdpa,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "configs": configs,
+            "reference_protocol": ref_proto,
+            "small_n_f16_causal_fwdbwd": small,
         }
         print(json.dumps(out))
     if dist is not None:
