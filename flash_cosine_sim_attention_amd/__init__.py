@@ -5,6 +5,6 @@ from .ops import (flash_cosine_sim_attention, plain_cosine_sim_attention, l2norm
                   FlashCosineSimAttention)
 from .ext import debug
 
-__version__ = '0.1.0'
+__version__ = '0.3.0'
 __all__ = ['flash_cosine_sim_attention', 'plain_cosine_sim_attention', 'l2norm_tensors', 'debug',
            'FlashCosineSimAttention']

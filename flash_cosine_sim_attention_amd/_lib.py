@@ -18,43 +18,65 @@ LIB_PATH = os.environ.get("FCSA_LIB") or os.path.join(_HERE, "libfcsa_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 FCSA_F32, FCSA_F16, FCSA_BF16 = 0, 1, 2
-ABI_VERSION = 2
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "fcsa.h")
 
 
-class Tensor(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("stride0", C.c_int64), ("stride1", C.c_int64), ("stride2", C.c_int64)]
+# ---- ctypes mirrors of the structs, GENERATED from include/fcsa.h (one source of truth for the layout; the compiled binding
+# csrc/fcsa_torch.cpp includes the same header) ----------------------------------------------------------------------------
+
+_SCALARS = {"int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float, "size_t": C.c_size_t,
+            "char": C.c_char, "int": C.c_int}
 
 
-class Problem(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("batch", C.c_int32), ("heads", C.c_int32), ("kv_heads", C.c_int32),
-                ("q_len", C.c_int32), ("k_len", C.c_int32), ("dim_head", C.c_int32), ("causal", C.c_int32),
-                ("bias_batch_dim", C.c_int32), ("l2norm_qk", C.c_int32), ("groups", C.c_int32), ("scale", C.c_float)]
+def _parse_header(path):
+    """{struct name: [(field, ctype)]} and {macro: int} from a C header that sticks to `typedef struct name { ... } name;`
+    with one declaration per line (comma-separated declarators allowed), pointer / scalar / nested-struct / char[N] fields."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(FCSA_\w+)\s+(-?\d+)\s*$", text, flags=re.M)}
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            head, _, names = decl.rpartition(" ")
+            while "," in head:                                   # `fcsa_tensor q, k, v` -> type = first token(s), names = the rest
+                head, _, more = head.rpartition(" ")
+                names = more + " " + names
+            base = head.replace("const", "").strip()
+            for nm in names.replace(",", " ").split():
+                stars = base.count("*") + nm.count("*")
+                nm = nm.strip("*")
+                tname = base.replace("*", "").strip()
+                arr = re.match(r"(\w+)\[(\d+)\]$", nm)
+                if stars:
+                    ct = C.c_void_p                              # every pointer is an opaque device / host address here
+                elif tname in structs:
+                    ct = structs[tname][1]
+                else:
+                    ct = _SCALARS[tname]
+                if arr:
+                    nm, ct = arr.group(1), ct * int(arr.group(2))
+                fields.append((nm, ct))
+        cls = type(m.group(3), (C.Structure,), {"_fields_": fields})
+        structs[m.group(3)] = (fields, cls)
+    return {k: v[1] for k, v in structs.items()}, macros
 
 
-class NormState(C.Structure):
-    _fields_ = [("qn", C.c_void_p), ("kn", C.c_void_p), ("rq", C.c_void_p), ("rk", C.c_void_p)]
+_STRUCTS, _MACROS = _parse_header(HEADER)
+ABI_VERSION = _MACROS["FCSA_ABI_VERSION"]
+Tensor = _STRUCTS["fcsa_tensor"]
+Problem = _STRUCTS["fcsa_problem"]
+NormState = _STRUCTS["fcsa_norm_state"]
+ForwardArgs = _STRUCTS["fcsa_forward_args"]
+BackwardArgs = _STRUCTS["fcsa_backward_args"]
+KernelStat = _STRUCTS["fcsa_kernel_stat"]
 
 
-class ForwardArgs(C.Structure):
-    _fields_ = [("p", Problem), ("q", Tensor), ("k", Tensor), ("v", Tensor), ("o", Tensor),
-                ("inv_l", C.c_void_p), ("mask", C.c_void_p), ("attn_bias", C.c_void_p),
-                ("norm", NormState), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
-
-
-class BackwardArgs(C.Structure):
-    _fields_ = [("p", Problem), ("d_out", Tensor), ("o", Tensor), ("inv_l", C.c_void_p),
-                ("q", Tensor), ("k", Tensor), ("v", Tensor), ("mask", C.c_void_p), ("attn_bias", C.c_void_p),
-                ("norm", NormState), ("dq", Tensor), ("dk", Tensor), ("dv", Tensor), ("d_bias", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p)]
-
-
-class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("calls", C.c_int32), ("total_ms", C.c_float), ("min_ms", C.c_float),
-                ("max_ms", C.c_float)]
-
-
-EXPORTS = ("fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_forward_workspace_bytes", "fcsa_l2norm", "fcsa_debug",
-           "fcsa_last_error", "fcsa_profile_enable", "fcsa_profile_collect")
+EXPORTS = ("fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_forward_workspace_bytes", "fcsa_forward_needs_qn",
+           "fcsa_l2norm", "fcsa_debug", "fcsa_last_error", "fcsa_profile_enable", "fcsa_profile_collect")
 
 _lib = None
 
@@ -90,6 +112,8 @@ def load():
     lib.fcsa_backward_workspace_bytes.restype = C.c_size_t
     lib.fcsa_forward_workspace_bytes.argtypes = [C.POINTER(Problem)]
     lib.fcsa_forward_workspace_bytes.restype = C.c_size_t
+    lib.fcsa_forward_needs_qn.argtypes = [C.POINTER(Problem), C.c_int32]
+    lib.fcsa_forward_needs_qn.restype = C.c_int
     lib.fcsa_l2norm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcsa_l2norm.restype = C.c_int
@@ -126,3 +150,27 @@ def profile_collect():
         raise RuntimeError("fcsa_profile_collect failed")
     return [dict(name=arr[i].name.decode(), calls=arr[i].calls, total_ms=arr[i].total_ms, min_ms=arr[i].min_ms,
                  max_ms=arr[i].max_ms) for i in range(min(n, 16))]
+
+
+# ---- helpers for code that drives the C ABI directly over torch tensors (tests, tools, ext.l2norm_device) ------------------
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+    return {torch.float32: FCSA_F32, torch.float16: FCSA_F16, torch.bfloat16: FCSA_BF16}[torch_dtype]
+
+
+def tensor4(t) -> "Tensor":
+    """fcsa_tensor over a 4-D torch tensor (element strides of the three leading dims)."""
+    assert t.dim() == 4 and t.stride(3) == 1
+    return Tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def problem(torch_dtype, dims, causal=False, bias_batch=False, l2norm_qk=True, groups=1, scale=8.0) -> "Problem":
+    """fcsa_problem; dims = (B, H, Hk, N, M, D)."""
+    B, H, Hk, N, M, D = dims
+    return Problem(dtype_code(torch_dtype), B, H, Hk, N, M, D, int(bool(causal)), int(bool(bias_batch)),
+                   int(bool(l2norm_qk)), int(groups if l2norm_qk else 1), float(scale))
+
+
+def forward_needs_qn(prob: "Problem", need_backward: bool) -> bool:
+    return bool(load().fcsa_forward_needs_qn(C.byref(prob), 1 if need_backward else 0))

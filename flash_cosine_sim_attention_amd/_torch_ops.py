@@ -46,7 +46,9 @@ def _register_fakes():
         o = q.new_empty(q.shape)
         none32, none = q.new_empty((0,), dtype=torch.float32), q.new_empty((0,))
         inv_l = torch.empty((B, H, N), **f32) if need_backward else none32
-        qn = q.new_empty((B, H, N, D)) if l2norm_qk else none
+        # (an inference call of the 16-bit kernels saves no normalised q: fcsa_forward_needs_qn, include/fcsa.h)
+        fusable = D % groups == 0 and (D // groups) % 8 == 0 and ((D // groups) // 8) & ((D // groups) // 8 - 1) == 0
+        qn = q.new_empty((B, H, N, D)) if (l2norm_qk and (need_backward or q.dtype == torch.float32 or not fusable)) else none
         kn = q.new_empty((B, Hk, M, D)) if l2norm_qk else none
         rq = torch.empty((B, H, N, groups), **f32) if (l2norm_qk and need_backward) else none32
         rk = torch.empty((B, Hk, M, groups), **f32) if (l2norm_qk and need_backward) else none32

@@ -63,29 +63,41 @@ def attention_forward_cpu(q, k, v, mask=None, attn_bias=None, scale=8.0, groups=
     if attn_bias is not None:
         bias = attn_bias.float().unsqueeze(1 if attn_bias_batch_dim else 0)          # [B,1,N,M] or [1,H,N,M]
     keep_keys = None if mask is None else mask.to(torch.bool)[:, None, None, :]      # [B,1,1,M]
-    shift = float(scale) * (groups if l2norm_qk else 1)   # upper bound of the logits (without bias): exp never overflows
     offset = M - N                                        # key j is visible to query i iff j <= i + offset (cu:1210)
 
+    # Running row max with rescale (the exponent shift of a row is its own largest visible logit so far): exact for ANY scale,
+    # groups, bias and for unnormalised q, k (l2norm_qk=False) -- a constant shift of scale * groups underflows whole rows to 0 once
+    # scale * groups is large, and overflows without the l2norm.
     acc = torch.zeros((B, H, N, D), dtype=torch.float32)
     total = torch.zeros((B, H, N, 1), dtype=torch.float32)
+    top = torch.full((B, H, N, 1), float("-inf"), dtype=torch.float32)
     for r0 in range(0, N, row_block):
         r1 = min(N, r0 + row_block)
         last = M if not causal else min(M, r1 + offset)   # keys >= last are invisible to every row of this block
         rows = qf[:, :, r0:r1]
-        a, s = acc[:, :, r0:r1], total[:, :, r0:r1]
+        a, s, t = acc[:, :, r0:r1], total[:, :, r0:r1], top[:, :, r0:r1]
         for c0 in range(0, max(last, 0), key_block):
             c1 = min(last, c0 + key_block)
             logits = torch.matmul(rows, kt[..., c0:c1]) * scale
             if bias is not None:
                 logits = logits + bias[:, :, r0:r1, c0:c1]
-            w = torch.exp(logits - shift)
+            visible = None
             if causal and c1 - 1 > r0 + offset:           # the block touches the diagonal
                 ii = torch.arange(r0, r1).unsqueeze(1) + offset
                 jj = torch.arange(c0, c1).unsqueeze(0)
-                w = w * (jj <= ii)
+                visible = (jj <= ii)
             if keep_keys is not None:
-                w = w * keep_keys[..., c0:c1]
+                visible = keep_keys[..., c0:c1] if visible is None else (visible & keep_keys[..., c0:c1])
+            if visible is not None:
+                logits = logits.masked_fill(~visible, float("-inf"))
+            t_new = torch.maximum(t, logits.amax(dim=-1, keepdim=True))
+            safe = torch.where(torch.isinf(t_new), torch.zeros_like(t_new), t_new)      # rows that have seen no key yet
+            w = torch.exp(logits - safe)
+            rescale = torch.exp(torch.where(torch.isinf(t), torch.zeros_like(t), t) - safe)
+            a.mul_(rescale)
+            s.mul_(rescale)
             a += torch.matmul(w, vf[:, :, c0:c1])
             s += w.sum(dim=-1, keepdim=True)
+            t.copy_(t_new)
     out = acc / total.clamp_min(1e-30)                    # rows without a valid key: 0 / tiny = 0
     return out.reshape(out_shape).to(out_dtype)

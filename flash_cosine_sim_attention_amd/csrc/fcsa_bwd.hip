@@ -28,58 +28,16 @@
 // sequential loops with one straight-line body each (no accumulator copies at if/else joins).
 #include <type_traits>
 
-// tuning knobs (row bytes D*ES up to which a kernel asks for 2 waves/SIMD, i.e. <= 256 registers)
-#ifndef FCSA_DKV_2W_BYTES
-#define FCSA_DKV_2W_BYTES 128
-#endif
-#ifndef FCSA_DKV_BMQ8
-#define FCSA_DKV_BMQ8 128      // staged query rows of the 8-wave dKV form
-#endif
-#ifndef FCSA_DKV_BMQ_WIDE
-#define FCSA_DKV_BMQ_WIDE 64   // staged query rows of the dKV kernel for 16-bit D >= 96 in the LDS-DMA form
-#endif
-#ifndef FCSA_DQ_2W_BYTES
-#define FCSA_DQ_2W_BYTES 128
-#endif
-#ifndef FCSA_DQ_PIPE
-#define FCSA_DQ_PIPE 1         // software-pipelined dQ tile where the kernel runs one wave per SIMD (16-bit D >= 96)
-#endif
-#ifndef FCSA_DQ_SUB_WIDE
-#define FCSA_DQ_SUB_WIDE 0      // measured: no gain from 128-key stages at one wave per SIMD
-#endif
-#ifndef FCSA_DQ_DMA
-#define FCSA_DQ_DMA 1          // K / V stages of the dQ kernel by LDS-DMA (16-bit types)
-#endif
-#ifndef FCSA_DKV_AHEAD      // 1: dKV kernel requests the next pass's first tile + K / V fragments from inside the current epilogue
-#define FCSA_DKV_AHEAD 1
-#endif
-#ifndef FCSA_DQ_SUB8         // 64-key tiles per LDS stage of the 8-wave dQ kernel, 16-bit types: 4 = 256-key stages (one barrier per 256 keys;
-                             // C3: -1.2 % against 128-key stages, although the epilogue scratch then no longer fits behind the stages)
-#define FCSA_DQ_SUB8 4
-#endif
-#ifndef FCSA_DQ_PIPE_ALL     // 1: the pipelined dQ tile also at two waves per SIMD (A/B builds; measured: no gain)
-#define FCSA_DQ_PIPE_ALL 0
-#endif
-#ifndef FCSA_DQ_AHEAD       // 1: dQ kernel requests the next iteration's first stage + row chunks before the current epilogue
-#define FCSA_DQ_AHEAD 1
-#endif
-#ifndef FCSA_DKV_EXP_UNDER_DP    // 1: pipelined dKV tile issues the exponentials of a block between the MFMAs of its dP chain (measured: +1.2 % time)
-#define FCSA_DKV_EXP_UNDER_DP 0
-#endif
-#ifndef FCSA_DKV_SPREAD      // 1: the LDS-DMA pieces of the next tile are issued one per 32-row block instead of all at the tile top (measured: +1.1 % time)
-#define FCSA_DKV_SPREAD 0
-#endif
-#ifndef FCSA_DKV_DMA
-#define FCSA_DKV_DMA 1         // Q / dO tiles of the pipelined dKV form by LDS-DMA (0: through registers, for A/B builds)
-#endif
-#ifndef FCSA_DKV_PIPE
-#define FCSA_DKV_PIPE 1        // software-pipelined dKV tile (16-bit types, no bias); 0 = the plain form, for A/B builds
-#endif
-
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
 
 namespace fcsa {
+// Tuning constants (each settled by a same-box A/B on MI355X; the rejected alternatives are listed in DESIGN.md §8):
+constexpr int kDq2WBytes = 128;      // row bytes D*ES up to which the dQ kernel asks for 2 waves / SIMD (<= 256 registers)
+constexpr int kDkv2WBytes = 128;     // same for the dKV kernel
+constexpr int kDqSub8 = 4;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
+constexpr int kDkvBmq8 = 128;        // staged query rows of the 8-wave dKV kernel
+constexpr int kDkvBmqWide = 64;      // staged query rows of the dKV kernel for 16-bit D >= 96 (LDS-DMA form)
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_dkv[128];
 __device__ unsigned long long g_trace_dq[128];
@@ -98,7 +56,7 @@ template <typename T, int D, bool MASKED, bool BIAS>
 FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
                       f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
-                      uint32_t ncm, int i, int j0, int diff, const char* bias_row, float* dbias_row, int m_lim) {
+                      uint32_t ncm, int i, int j0, int diff, const char* bias_row, int m_lim) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
@@ -145,29 +103,6 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
       for (int r = 0; r < 16; ++r) pe[r] = ((w >> crow(r, 0)) & 1u) ? pe[r] : 0.f;
     }
     mul16(s, pe, dp);                    // dS; dp already holds dP - delta
-    if constexpr (BIAS) {                // d_bias += dS: rows owned by this lane alone (see bwd_dq_kernel), 4 consecutive keys per rq
-      if (dbias_row != nullptr) {
-        if ((p.M & 3) == 0) {            // 16-byte aligned groups (wave-uniform test)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const int j = jbase + 8 * rq;
-            if (j < m_lim) {
-              f32x4* g = reinterpret_cast<f32x4*>(dbias_row + j);
-              f32x4 a = *g;
-#pragma unroll
-              for (int e4 = 0; e4 < 4; ++e4) a[e4] += s[4 * rq + e4];
-              *g = a;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int j = jbase + crow(r, 0);
-            if (j < m_lim) dbias_row[j] += s[r];
-          }
-        }
-      }
-    }
     SecondB<T> pb;
     pb.prep(s);
 #pragma unroll
@@ -250,20 +185,20 @@ FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, co
 // the scratch fits behind them.
 template <typename T, int D, int NW, int SUB> struct DqLds
     : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB,
-             FCSA_DQ_DMA && FCSA_DQ_AHEAD && Traits<T>::ES == 2 && (64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
-             ((NW == 8 || D * Traits<T>::ES > FCSA_DQ_2W_BYTES) ? 160 : 80) * 1024> {};
+             Traits<T>::ES == 2 && (64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+             ((NW == 8 || D * Traits<T>::ES > kDq2WBytes) ? 160 : 80) * 1024> {};
 
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
 template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
     : EpiLds<T, D, NW, 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4),
-             FCSA_DKV_PIPE && FCSA_DKV_DMA && FCSA_DKV_AHEAD && Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
-             ((NW == 8 || D * Traits<T>::ES > FCSA_DKV_2W_BYTES) ? 160 : 80) * 1024> {};
+             Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+             ((NW == 8 || D * Traits<T>::ES > kDkv2WBytes) ? 160 : 80) * 1024> {};
 
 // SUB = 64-key tiles per LDS stage: 1, or 2 / 4 in the 8-wave form (one workgroup per CU has the LDS for 128- / 256-key stages).
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
 template <typename T, int D, int NW, bool BIAS, int SUB>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDq2WBytes ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64, BNS = BN * SUB;
@@ -280,15 +215,10 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   // causal: a workgroup takes the PAIR of row tiles (MT-1-pt, pt) -> constant work per workgroup (see fwd_kernel)
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  // d_bias[h or b, i, j] = sum over the OTHER index (batch for a per-head bias, heads for a per-batch bias) of dS[b, h, i, j].
-  // The product path computes it in bwd_dbias_kernel (below) and calls this kernel with p.d_bias == nullptr.  The in-kernel form
-  // is kept for A/B builds (FCSA_DBIAS_KERNEL=0 in fcsa_capi.hip): a workgroup OWNS (bias slice, row tile[, key range]), runs the
-  // reduced index sequentially (`red` loop) and adds each dS block to d_bias with plain read-modify-writes of rows only this wave
-  // ever touches -- deterministic, no atomics, but 2x slower at C2.  Without a d_bias pointer: one (batch, head) per workgroup.
-  const bool own_bias = BIAS && p.d_bias != nullptr;
-  const int n_red = own_bias ? (p.bias_batch ? p.H : p.B) : 1;
-  int owner, pt;
-  block_to_work(blockIdx.x, own_bias ? (p.bias_batch ? p.B : p.H) : p.B * p.H, PT, owner, pt);
+  // (d_bias is not this kernel's business: bwd_dbias_kernel below recomputes the dS tiles of a bias slice and writes it once)
+  int bh, pt;
+  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
+  const int b = bh / p.H, h = bh % p.H;
   const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
   // split-key launches (gridDim.y = p.dq_splits > 1; never causal): this workgroup sees the keys [k_lo, k_lo + Mk) only and
   // writes its partial dQ^ (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
@@ -315,7 +245,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
   // K / V stages: LDS-DMA for 16-bit types (no staging registers, no ds_write passes; see DmaStager), else through registers.
-  constexpr bool DMA = FCSA_DQ_DMA && TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
+  constexpr bool DMA = TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
   // SEP: the epilogue scratch has its own LDS bytes behind the staging buffers.  Then nothing of one (row tile) iteration has to
   // be finished before the next one starts loading: the first K / V stage and this lane's Q^ / dO / O row chunks of the NEXT
   // iteration are requested before the epilogue of the current one and land while it runs (the pass marks of the WG trace showed
@@ -392,9 +322,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
       EP::load_inv(rinv_n, p.rq + (((int64_t)b_ * p.H + h_) * p.N + m0_ + wave * 32) * p.G, p.G, p.lgm, ln, rows_valid_);
   };
 
-  for (int red = 0; red < n_red; ++red) {
-  const int b = own_bias ? (p.bias_batch ? owner : red) : owner / p.H;
-  const int h = own_bias ? (p.bias_batch ? red : owner) : owner % p.H;
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
   int m0, nt;
@@ -441,7 +368,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
   delta = xhalf_sum(delta);
   if (i < p.N) {
     const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
-    lc = __builtin_amdgcn_logf(rinvl) - p.c2;     // v_log_f32 = log2
+    lc = (p.invl_log2 ? rinvl : __builtin_amdgcn_logf(rinvl)) - p.c2;     // v_log_f32 = log2
     if (fa.hi == 0 && blockIdx.y == 0) p.delta[ridx] = delta;
   }
 
@@ -453,11 +380,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
 
   const uint8_t* mrow = p.mask ? p.mask + (int64_t)b * p.M + k_lo : nullptr;
   const char* bias_row = nullptr;                 // row min(i, N-1): always a valid address
-  float* dbias_row = nullptr;                     // only for real rows
   if constexpr (BIAS) {
     const int64_t boff = ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M + k_lo;      // first key of this workgroup's range
     bias_row = p.bias + boff * (int64_t)sizeof(typename TR::elem);
-    if (p.d_bias != nullptr && i < p.N) dbias_row = p.d_bias + boff;
   }
 
   // stages u = t / SUB of SUB 64-key tiles: loads of stage u+1 are issued at the first tile of stage u, stored after its last
@@ -529,7 +454,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
         }
       }
       FCSA_STAMP(ts, 1);
-      if constexpr (FCSA_DQ_PIPE && TR::ES == 2 && !BIAS && (FCSA_DQ_PIPE_ALL || D * TR::ES > FCSA_DQ_2W_BYTES)) {      // one wave per SIMD only
+      if constexpr (TR::ES == 2 && !BIAS && D * TR::ES > kDq2WBytes) {      // pipelined tile: one wave per SIMD only
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
@@ -537,9 +462,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
                                               next_here ? t + 1 : -1, t, fa, qf, dof, dq, lc, delta, word, ncm, i, j0, diff, pipe);
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (j0 > mw + 31 + diff);
-        if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, dbias_row, Mk);
+        if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
       } else {
-        dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, dbias_row, Mk);
+        dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
       }
       FCSA_STAMP(ts, 2);
       if (last_of_stage) {                                 // workgroup-uniform
@@ -584,10 +509,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
     if (rows_valid > 0) EP::put(scr, dq, p.scale, le, xreg ? qf : nullptr, xs, LDS::XPITCH);                  // cu:1580-1582: dS *= scale
     have_pre = false;
     if constexpr (SEP) {
-      const bool next_pass = pass + 1 < npass, next_red = red + 1 < n_red;
-      if (next_pass || next_red) {
-        const int rn = next_pass ? red : red + 1;
-        request_ahead(own_bias ? (p.bias_batch ? owner : rn) : b, own_bias ? (p.bias_batch ? rn : owner) : h, next_pass ? pass + 1 : 0);
+      if (pass + 1 < npass) {
+        request_ahead(b, h, pass + 1);
         have_pre = true;
       }
     }
@@ -598,12 +521,11 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DQ_2W_BYTE
                                   rinv, p.lgm, p.norm_eps);
     }
     if constexpr (!SEP) {
-      if (pass + 1 < npass || red + 1 < n_red) __syncthreads();      // the scratch overlaps the staging buffers of the next iteration
+      if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
     }
   }
   FCSA_PASS_MARK(4);
   }   // pass
-  }   // red
 #undef FCSA_PASS_MARK
 #ifdef FCSA_TRACE_WG
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) { g_trace_wg_dq[2 * blockIdx.x] = trace_t0; g_trace_wg_dq[2 * blockIdx.x + 1] = trace_now(); }
@@ -648,11 +570,13 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
   const int m0 = mt * BM, mw = m0 + wave * 32, i = mw + (lane & 31);
   const int diff = p.M - p.N;
   const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
+  typedef typename TR::elem E;                                           // d_bias has the dtype of the bias (cu:1912 casts; here it is written once)
+  E* const dbias = reinterpret_cast<E*>(p.d_bias);
   if (p.causal && j0 > m0 + BM - 1 + diff) {                             // tile entirely above the diagonal: d_bias = 0 (workgroup-uniform)
     for (int e = tid; e < BM * (BN / 4); e += NT) {
       const int row = m0 + e / (BN / 4), col = j0 + 4 * (e % (BN / 4));
       if (row < p.N)
-        for (int c = col; c < min(col + 4, p.M); ++c) p.d_bias[((int64_t)owner * p.N + row) * p.M + c] = 0.f;
+        for (int c = col; c < min(col + 4, p.M); ++c) dbias[((int64_t)owner * p.N + row) * p.M + c] = (E)0.f;
     }
     return;
   }
@@ -712,7 +636,7 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
       qf[kk] = p.q_scaled ? nq[kk] : scale_frag<T>(nq[kk], p.c1);
       dof[kk] = ndo[kk];
     }
-    const float lc = i < p.N ? __builtin_amdgcn_logf(ninvl) - p.c2 : 0.f, delta = i < p.N ? ndelta : 0.f;
+    const float lc = i < p.N ? (p.invl_log2 ? ninvl : __builtin_amdgcn_logf(ninvl)) - p.c2 : 0.f, delta = i < p.N ? ndelta : 0.f;
     const uint64_t word = __ballot((j0 + lane) < p.M && nmask != 0);     // valid keys of this tile for this batch element
     __syncthreads();                                                      // the previous iteration's fragment reads are done
     sk.store(smem, tid);
@@ -756,12 +680,17 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
       const int row = 4 * pp + (lane >> 4), col = 4 * (lane & 15);
       const f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * OPITCH + col * 4);
       if (mw + row < p.N) {
-        float* o = p.d_bias + ((int64_t)owner * p.N + mw + row) * (int64_t)p.M + j0 + col;
-        if (vec && j0 + col + 3 < p.M) {
-          *reinterpret_cast<f32x4*>(o) = v;
+        E* o = dbias + ((int64_t)owner * p.N + mw + row) * (int64_t)p.M + j0 + col;
+        if (vec && j0 + col + 3 < p.M) {      // 16 lanes write one row's 64 keys: 256 (f32) / 128 (16 bit) contiguous bytes
+          if constexpr (TR::ES == 4) {
+            *reinterpret_cast<f32x4*>(o) = v;
+          } else {
+            const u32x2 u = {TR::pack2(v[0], v[1]), TR::pack2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(o) = u;
+          }
         } else {
           for (int c = 0; c < 4; ++c)
-            if (j0 + col + c < p.M) o[c] = v[c];
+            if (j0 + col + c < p.M) o[c] = (E)v[c];
         }
       }
     }
@@ -885,11 +814,11 @@ struct DkvPipe {
   }
 };
 
-template <typename T, int D, int BMQ, bool MASKED, typename Hook>
+template <typename T, int D, int BMQ, bool MASKED>
 FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                             const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                             f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts, Hook&& hook) {
+                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int NB = BMQ / 32;
@@ -905,10 +834,8 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     f32x16 s = pp_.s, dp = pp_.dp;
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.qa[kk], kf[kk], s);
-#if !FCSA_DKV_EXP_UNDER_DP
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(pp_.da[kk], vf[kk], dp);
-#endif
     // ---- T: transposed fragments of this block (dO^T for dV, Q^T for dK)
     u32x4 td[G::DB][2], tq[G::DB][2];
 #pragma unroll
@@ -923,24 +850,10 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     }
     FCSA_FENCE();
     if (ib == 1) FCSA_STAMP(ts, 3);
-    hook(ib);      // this block's share of the next tile's LDS-DMA requests
-    FCSA_FENCE();
-    // ---- X: P = exp2(s), dS = P * (dP - delta), packed in place.  The exponentials need S only: they are issued between the
-    //      MFMAs of the dP chain (same wave: the VALU works while the matrix pipe runs that chain), the products after it.
+    // ---- X: P = exp2(s), dS = P * (dP - delta), packed in place
     f32x16 pr;
-#if FCSA_DKV_EXP_UNDER_DP
-#pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(pp_.da[kk], vf[kk], dp);
-#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(s[r]);
-#if FCSA_DKV_EXP_UNDER_DP
-#pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) {
-      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                   // one MFMA of the dP chain
-      __builtin_amdgcn_sched_group_barrier(0x400, (16 + G::KS - 1) / G::KS, 0);          // its share of the 16 exponentials
-    }
-#endif
     if constexpr (MASKED) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) pr[r] = ((w >> crow(r, 0)) & 1u) ? pr[r] : 0.f;
@@ -977,12 +890,12 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
 }
 
 template <typename T, int D, int NW, int BMQ, bool BIAS>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYTES ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BMQ * G::ROWB;
-  constexpr bool PIPE = FCSA_DKV_PIPE && Traits<T>::ES == 2 && !BIAS;
+  constexpr bool PIPE = Traits<T>::ES == 2 && !BIAS;      // software-pipelined tile (dkv_tile_pipe)
   constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 4;                // Q tile | dO tile | lc[BMQ] | -delta[BMQ]
   static_assert(BMQ % 32 == 0 && BMQ <= NT, "query tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF_B]
@@ -1021,7 +934,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
   // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
-  constexpr bool DMA = PIPE && FCSA_DKV_DMA && (BMQ * G::ROWB) % 1024 == 0;
+  constexpr bool DMA = PIPE && (BMQ * G::ROWB) % 1024 == 0;
   typedef DkvLds<T, D, NW, BMQ, BIAS> LDS;
   constexpr bool SEP = LDS::SEP;      // see bwd_dq_kernel: the next pass is requested from inside the epilogue of the current one
   Stager<T, D, BMQ, NT> sq, sdo;
@@ -1145,7 +1058,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
     if (tid < BMQ) {
       {
         // rows beyond N: lc = -inf makes P exactly 0 there
-        reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? __builtin_amdgcn_logf(lc_r) - p.c2 : -INFINITY;
+        reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = row_ok ? (p.invl_log2 ? lc_r : __builtin_amdgcn_logf(lc_r)) - p.c2 : -INFINITY;
         reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = row_ok ? -dl_r : 0.f;      // -delta
       }
     }
@@ -1205,41 +1118,27 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= FCSA_DKV_2W_BYT
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
       if constexpr (PIPE && DMA) {
-        // The next tile arrives by LDS-DMA, one piece per wave at a time spread over this tile's blocks
+        // the next tile arrives by LDS-DMA, all pieces requested at the top of this tile
         if (more) {
           advance(t + 1);
           load_rows(i0 + BMQ);
         }
         const uint32_t lds_nxt = lds0 + (par ^ 1) * BUF_B;
         FCSA_STAMP(ts, 1);
-        constexpr int NB = BMQ / 32, NP = 2 * DS::PER;
-        auto share = [&](int ib) {
-          if (more) {
-#pragma unroll
-            for (int k = FCSA_DKV_SPREAD ? ib * NP / NB : (ib == 0 ? 0 : NP); k < (FCSA_DKV_SPREAD ? (ib + 1) * NP / NB : NP); ++k) {
-              if (k < DS::PER) dq_.issue_piece(stq, lds_nxt, k, wave);
-              else ddo_.issue_piece(stdo, lds_nxt + TILE_B, k - DS::PER, wave);
-            }
-          }
-        };
+        if (more) {
+          dq_.issue(stq, lds_nxt, wave);
+          ddo_.issue(stdo, lds_nxt + TILE_B, wave);
+        }
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
-        if constexpr (!FCSA_DKV_SPREAD) {
-          share(0);
-          if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, [](int) {});
-        } else if (!skip) {
-          dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, share);
-        } else {
-#pragma unroll
-          for (int ib = 0; ib < NB; ++ib) share(ib);
-        }
+        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
       } else {
       if (more) load_tile(t + 1, nxt);
       FCSA_STAMP(ts, 1);
       if constexpr (PIPE) {
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
-        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, [](int) {});
+        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
         const int next_i0 = more ? i0 + BMQ : -1;
@@ -1351,9 +1250,6 @@ namespace fcsa {
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
 static int tile_waves(int64_t batch_heads, int len, bool causal) {
-#ifdef FCSA_FORCE_NW4      // A/B builds only
-  return 4;
-#endif
   const int MT = (len + 255) / 256;
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
@@ -1366,22 +1262,19 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   // 128-key stages (one barrier per 128 keys) in the 8-wave form and, with LDS-DMA staging (no staging registers), also for the
   // one-wave-per-SIMD configurations (16-bit D >= 96: one workgroup per CU, the LDS is there)
   // 8-wave form: 256-key stages where they arrive by LDS-DMA (no staging registers), 128-key stages through registers (f32)
-  constexpr int SUB = NW == 8 ? ((FCSA_DQ_DMA && Traits<T>::ES == 2) ? FCSA_DQ_SUB8 : 2)
-                              : (FCSA_DQ_SUB_WIDE && FCSA_DQ_DMA && Traits<T>::ES == 2 && D * Traits<T>::ES > FCSA_DQ_2W_BYTES) ? 2 : 1;
+  constexpr int SUB = NW == 8 ? (Traits<T>::ES == 2 ? kDqSub8 : 2) : 1;
   const size_t lds = DqLds<T, D, NW, SUB>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
   auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-  // with a d_bias request a workgroup owns (bias slice, row tile) and loops over the reduced index itself (see the kernel)
-  const int64_t owners = (BIAS && p.d_bias != nullptr) ? (p.bias_batch ? p.B : p.H) : (int64_t)p.B * p.H;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(owners * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4>(p, s);       // split-key path: 128-row tiles x key ranges
-  if constexpr (D * Traits<T>::ES <= FCSA_DQ_2W_BYTES) {
+  if constexpr (D * Traits<T>::ES <= kDq2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8>(p, s);
   }
   return launch_dq_nw<T, D, BIAS, 4>(p, s);
@@ -1394,8 +1287,8 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   // else 64; 128 in the 8-wave form (one workgroup per CU: the LDS is there, and half the barriers per key tile: -4.5%)
   // (the pipelined LDS-DMA form has no staging registers: wide rows can take deeper tiles too -> fragment prefetch across
   //  blocks, fewer barriers)
-  constexpr bool DMA_FORM = FCSA_DKV_PIPE && FCSA_DKV_DMA && Traits<T>::ES == 2 && !BIAS;
-  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? FCSA_DKV_BMQ_WIDE : 32) : (NW == 8 ? FCSA_DKV_BMQ8 : 64);
+  constexpr bool DMA_FORM = Traits<T>::ES == 2 && !BIAS;
+  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? kDkvBmqWide : 32) : (NW == 8 ? kDkvBmq8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
@@ -1409,7 +1302,7 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
-  if constexpr (D * Traits<T>::ES <= FCSA_DKV_2W_BYTES) {
+  if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
   }
   return launch_dkv_nw<T, D, BIAS, 4>(p, s);

@@ -48,13 +48,12 @@ int check_problem(const fcsa_problem& p) {
   if (p.l2norm_qk) {
     if (p.groups < 1 || p.dim_head % p.groups != 0)
       return fail(FCSA_ERR_INVALID_ARG, "groups (%d) must divide dim_head (%d)", p.groups, p.dim_head);
-    if (p.scale * (float)p.groups > 87.f)
-      return fail(FCSA_ERR_UNSUPPORTED, "scale * groups = %g > 87: exp of the logit range leaves f32 (saved row sums)",
-                  (double)(p.scale * (float)p.groups));
+    if (p.dtype == FCSA_F16 && fabsf(p.scale) * kLog2e > 60000.f)
+      return fail(FCSA_ERR_UNSUPPORTED, "float16: scale %g puts scale * log2(e) * q^ outside the type", (double)p.scale);
   } else if (p.groups != 1) {
     return fail(FCSA_ERR_INVALID_ARG, "groups must be 1 when l2norm_qk is 0");
   }
-  if (!(p.scale == p.scale)) return fail(FCSA_ERR_INVALID_ARG, "scale is NaN");
+  if (!(p.scale == p.scale) || std::isinf(p.scale)) return fail(FCSA_ERR_INVALID_ARG, "scale is NaN or infinite");
   return FCSA_OK;
 }
 
@@ -101,18 +100,19 @@ fcsa::View contiguous_view(void* p, int64_t heads, int64_t len, int64_t d, int e
 // A static shift only works while the whole logit range [-scale*groups, +scale*groups] fits the exponent range of the type
 // P~ is rounded to.  Real rows peak far below the theoretical bound once groups > 1 (found by the fuzz test: f16,
 // groups >= 4, scale >= 8 underflowed every P~ of a row to 0; the reference's shift = scale overflows there instead).
-// Beyond the safe range the forward kernel finds each row's max logit first and shifts by that ("dynamic"); the saved
-// inv_l then uses shift 0, i.e. it is 1 / sum_j exp(S_ij), which stays inside f32 for scale*groups <= 87.
+// Beyond the safe range the forward kernel finds each row's max logit first and shifts by that ("dynamic"); what it saves
+// for the backward is then log2(1 / sum_j exp(S_ij)) -- the value the backward kernels seed their S accumulators with anyway --
+// so nothing ever holds exp() of the full logit range and there is no limit on scale * groups.
 bool dynamic_shift(const fcsa_problem& p) {
   if (!p.l2norm_qk) return false;
-  const float bound = p.scale * (float)p.groups;
+  const float bound = fabsf(p.scale) * (float)p.groups;
   return p.dtype == FCSA_F16 ? bound > 11.f : bound > 60.f;
 }
 
 float exponent_shift(const fcsa_problem& p) {
   if (!p.l2norm_qk) return p.scale;
   if (dynamic_shift(p)) return 0.f;
-  const float bound = p.scale * (float)p.groups;
+  const float bound = fabsf(p.scale) * (float)p.groups;
   if (p.dtype == FCSA_F16) return bound - 10.f;
   return bound - 40.f > p.scale ? bound - 40.f : p.scale;
 }
@@ -135,27 +135,15 @@ struct BwdLayout {
 
 // Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
 // workgroups for 256 CUs), the problem is not causal and every split keeps >= 512 keys.  Mirrors forward_splits: C4 (1 x 8 heads x
-// 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  `owners`: (batch, head) pairs that get a workgroup per row tile --
-// batch * heads, or with a d_bias request only the bias slices (heads, or batches for a per-batch bias): there a workgroup
-// owns (bias slice, row tile, key range) and loops over the reduced index, so the grid is small exactly when it is slow.
-#ifndef FCSA_DBIAS_KERNEL
-#define FCSA_DBIAS_KERNEL 1
-#endif
-int dq_splits_for(const fcsa_problem& p, int64_t owners, int min_keys) {
+// 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  The ONE definition both the workspace size and the launch use.
+int backward_dq_splits(const fcsa_problem& p) {
   if (p.causal) return 1;
-  const int64_t wgs = owners * ((p.q_len + 127) / 128);
+  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
   if (wgs <= 0 || wgs >= 128) return 1;
   int64_t s = (256 + wgs - 1) / wgs;
   if (s > 16) s = 16;
-  if (s > p.k_len / min_keys) s = p.k_len / min_keys;
+  if (s > p.k_len / 512) s = p.k_len / 512;
   return s >= 2 ? (int)s : 1;
-}
-int64_t bias_owners(const fcsa_problem& p) { return p.bias_batch_dim ? p.batch : p.heads; }
-// workspace sizing: the larger of the two (the caller may or may not pass d_bias)
-int backward_dq_splits(const fcsa_problem& p) {
-  // (a bias owner runs its key range once per reduced index: shorter ranges still amortise the workgroup's fixed cost)
-  const int a = dq_splits_for(p, (int64_t)p.batch * p.heads, 512), b = dq_splits_for(p, bias_owners(p), 128);
-  return a > b ? a : b;
 }
 
 int log2_blocks_per_group(const fcsa_problem& p) {     // log2(group size / 8), or -1 if not a power of two of 8-blocks
@@ -328,8 +316,9 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.o = view(a->o, es);
   if (p.l2norm_qk) {
     const fcsa_norm_state& n = a->norm;
-    if (n.qn == nullptr || n.kn == nullptr)
-      return fail(FCSA_ERR_INVALID_ARG, "l2norm_qk needs norm.qn and norm.kn buffers");
+    if (n.kn == nullptr) return fail(FCSA_ERR_INVALID_ARG, "l2norm_qk needs the norm.kn buffer");
+    if (n.qn == nullptr && fcsa_forward_needs_qn(&p, a->inv_l != nullptr || n.rq != nullptr))
+      return fail(FCSA_ERR_INVALID_ARG, "l2norm_qk needs the norm.qn buffer for this problem (fcsa_forward_needs_qn)");
     fcsa::NormParams nq, nk;
     nq.eps = nk.eps = 1e-12f;
     nq.D = nk.D = p.dim_head; nq.G = nk.G = p.groups;
@@ -364,7 +353,7 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.qn_out = fuse_q ? static_cast<char*>(a->norm.qn) : nullptr;
   fp.rq_out = fuse_q ? a->norm.rq : nullptr;
   fp.G = p.groups; fp.lgm = fuse_q ? log2_blocks_per_group(p) : 0; fp.norm_eps = 1e-12f;
-  fp.dyn = dynamic_shift(p) ? 1 : 0;
+  fp.dyn = dynamic_shift(p) ? 1 : 0;      // then inv_l holds log2 of the normaliser
   fp.splits = 1; fp.ws_o = nullptr; fp.ws_l = nullptr;
   if (a->workspace != nullptr && a->attn_bias == nullptr) {
     const int sp = forward_splits(p);
@@ -377,6 +366,12 @@ int fcsa_forward(const fcsa_forward_args* a) {
     }
   }
   return timed("fwd", "forward", s, [&] { return fcsa::launch_forward(p.dtype, p.dim_head, fp, s); });
+}
+
+int fcsa_forward_needs_qn(const fcsa_problem* p, int32_t need_backward) {
+  if (p == nullptr || !p->l2norm_qk) return 0;
+  if (need_backward) return 1;
+  return (p->dtype != FCSA_F32 && fusable_groups(*p)) ? 0 : 1;
 }
 
 size_t fcsa_backward_workspace_bytes(const fcsa_problem* p) {
@@ -427,11 +422,8 @@ int fcsa_backward(const fcsa_backward_args* a) {
   // split-key dQ needs (batch, head) to be one flat index of the dq output (the finalize kernel sums the partial slabs per
   // (batch * head) row block); otherwise the unsplit kernel runs
   const bool dq_flat = a->dq.stride0 == (int64_t)p.heads * a->dq.stride1;
-  // d_bias: by the dedicated kernel (default), or by dQ workgroups that own a bias slice (FCSA_DBIAS_KERNEL=0 builds, for A/B)
   const bool want_dbias = a->attn_bias != nullptr && a->d_bias != nullptr;
-  const bool own_bias = want_dbias && !FCSA_DBIAS_KERNEL;
-  const int want_splits = own_bias ? dq_splits_for(p, bias_owners(p), 128) : dq_splits_for(p, (int64_t)p.batch * p.heads, 512);
-  const int dq_splits = (want_splits > 1 && want_splits <= L.dq_splits && dq_flat) ? want_splits : 1;
+  const int dq_splits = (L.dq_splits > 1 && dq_flat) ? L.dq_splits : 1;
   const bool dq_slab = dq_splits > 1 || (p.l2norm_qk != 0 && !L.fuse_norm);
   bp.dq_splits = dq_splits;
   bp.dq_split_stride = (int64_t)p.q_len * p.dim_head * 4;
@@ -452,11 +444,12 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.delta = reinterpret_cast<float*>(ws + L.delta);
   bp.mask = a->mask;
   bp.bias = static_cast<const char*>(a->attn_bias);
-  bp.d_bias = own_bias ? a->d_bias : nullptr;
+  bp.d_bias = a->d_bias;
   bp.B = p.batch; bp.H = p.heads; bp.N = p.q_len; bp.M = p.k_len;
   bp.causal = p.causal; bp.bias_batch = p.bias_batch_dim;
   bp.c1 = p.scale * kLog2e;
   bp.c2 = exponent_shift(p) * kLog2e;
+  bp.invl_log2 = dynamic_shift(p) ? 1 : 0;
   bp.bias_c = kLog2e;
   bp.scale = p.scale;
   bp.q_scaled = p.l2norm_qk ? 1 : 0;
@@ -467,8 +460,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
   if (int rc = timed("bwd_dq", "backward dq", s, [&] { return fcsa::launch_backward_dq(p.dtype, p.dim_head, bp, s); })) return rc;
   if (int rc = timed("bwd_dkv", "backward dkv", s, [&] { return fcsa::launch_backward_dkv(p.dtype, p.dim_head, bp, s); })) return rc;
-  if (want_dbias && !own_bias) {
-    bp.d_bias = a->d_bias;
+  if (want_dbias) {      // d_bias from recomputed dS tiles; needs delta, which the dQ kernel published
     if (int rc = timed("bwd_dbias", "backward d_bias", s, [&] { return fcsa::launch_backward_dbias(p.dtype, p.dim_head, bp, s); })) return rc;
   }
 

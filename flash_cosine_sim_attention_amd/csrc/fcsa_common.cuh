@@ -40,9 +40,6 @@ typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
 
 #define FCSA_DEV __device__ __forceinline__
-#ifndef FCSA_PK_MUL
-#define FCSA_PK_MUL 0      // measured on C3: v_pk_mul_f32 for dS is SLOWER (dq +2.7 %, dkv +1.4 %)
-#endif
 
 // NOTE: always pass vector ELEMENTS through this by-value helper.  `__builtin_bit_cast(float, v[t])`
 // applied directly to an ext_vector element lvalue is miscompiled by hipcc 7.2 (it reads element 0
@@ -792,21 +789,10 @@ FCSA_DEV unsigned long long trace_now() { unsigned long long v; asm volatile("s_
 
 FCSA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (2^x, quarter rate)
 
-// out[r] = a[r] * b[r] over a 16-register block, two values per instruction (v_pk_mul_f32: packed f32 runs at twice the
-// scalar-f32 rate on CDNA3/4, and every VALU issue slot taken from the partner wave's MFMA stream counts)
+// out[r] = a[r] * b[r] over a 16-register block (plain v_mul_f32: the v_pk_mul_f32 form measured slower)
 FCSA_DEV void mul16(f32x16& out, const f32x16& a, const f32x16& b) {
-#if FCSA_PK_MUL
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 x = {a[r], a[r + 1]}, y = {b[r], b[r + 1]};
-    const f32x2 z = x * y;
-    out[r] = z[0];
-    out[r + 1] = z[1];
-  }
-#else
 #pragma unroll
   for (int r = 0; r < 16; ++r) out[r] = a[r] * b[r];
-#endif
 }
 
 

@@ -37,19 +37,10 @@
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
 
-#ifndef FCSA_FWD_QPRE        // 1: the second pass's raw q rows are requested before the first pass's epilogue (measured: +0.7 % time)
-#define FCSA_FWD_QPRE 0
-#endif
-#ifndef FCSA_FWD_SUB         // 64-key tiles per LDS stage of the forward kernel where the stages arrive by LDS-DMA.  2 (one barrier per 128
-                             // keys, as in the backward kernels) measured +1.8 % time at C3: the forward's barrier sits in the MIDDLE of a tile
-                             // (mid()), where the old wave of a SIMD waits less than at a tile end; 1 it stays
-#define FCSA_FWD_SUB 1
-#endif
-#ifndef FCSA_FWD_DMA
-#define FCSA_FWD_DMA 1         // K / V tiles of the 32-rows-per-wave forward kernel by LDS-DMA (16-bit types)
-#endif
-
 namespace fcsa {
+// 64-key tiles per LDS stage of fwd_kernel where the stages arrive by LDS-DMA.  One: this kernel's barrier sits in the MIDDLE of a
+// tile (mid()), where the old wave of a SIMD waits less than at a tile end; two per stage measured +1.8 % time at C3.
+constexpr int kFwdSub = 1;
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
 #endif
@@ -279,7 +270,7 @@ FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const Frag
         qf[kk] = scale_frag<T>(qf[kk], r * p.c1);
         if (i < p.N) {
           const int c = 2 * kk + fa.hi;
-          *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];
+          if (p.qn_out != nullptr) *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];      // (inference: nothing is saved)
           if (p.rq_out != nullptr && (c & ((1 << p.lgm) - 1)) == 0) p.rq_out[row * p.G + (c >> p.lgm)] = r;
         }
       }
@@ -299,10 +290,10 @@ FCSA_DEV void load_q_frags(const FwdParams& p, int b, int h, int i, const FragAd
   finish_q_frags<T, D>(p, b, h, i, fa, qf);
 }
 
-// 64-key tiles per LDS stage of fwd_kernel (kernel and launcher must agree): FCSA_FWD_SUB with LDS-DMA staging and no dynamic-shift
+// 64-key tiles per LDS stage of fwd_kernel (kernel and launcher must agree): kFwdSub with LDS-DMA staging and no dynamic-shift
 // pre-pass (which stages single tiles through the same buffers), else 1
 template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
-  return (FCSA_FWD_DMA && !DYN && Traits<T>::ES == 2 && (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0) ? FCSA_FWD_SUB : 1;
+  return (!DYN && Traits<T>::ES == 2 && (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0) ? kFwdSub : 1;
 }
 
 // DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
@@ -356,8 +347,6 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 #else
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
-  u32x4 qpre[G::KS];      // raw q row chunks of the NEXT pass, in flight while the current pass's epilogue runs
-  bool have_qpre = false;
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
   const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
@@ -376,7 +365,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   // at the top of tile t into the buffer whose last reads finished before the barrier of tile t-1, and waited for right before
   // the barrier of tile t.  The FIRST tile is issued here, ahead of the Q fragments and their fused l2norm, so that its
   // HBM / L2 latency hides under that work (the previous pass ended with a barrier: the buffers are free).
-  constexpr bool DMA = FCSA_FWD_DMA && TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
+  constexpr bool DMA = TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
   constexpr bool EARLY = DMA && !DYN;             // (the dynamic-shift pre-pass stages through the same buffers first)
   Stager<T, D, BN, NT> sk, sv;
   typedef DmaStager<T, D, DMA ? BN * SUB : 1024, NW> DS;
@@ -403,12 +392,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   }
 
   u32x4 qf[G::KS];
-  if (have_qpre) {      // this pass's raw q rows were requested before the previous pass's epilogue
-#pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) qf[kk] = qpre[kk];
-  } else {
-    request_q_rows<T, D>(p, b, h, i, fa.hi, qf);
-  }
+  request_q_rows<T, D>(p, b, h, i, fa.hi, qf);
   finish_q_frags<T, D>(p, b, h, i, fa, qf);
   FCSA_PASS_MARK(1);
 
@@ -623,16 +607,12 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
     continue;
   }
   const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift
-  // saved for the backward in the GLOBAL shift convention (DYN: shift 0, i.e. 1 / sum_j exp(S_ij))
-  if (i < p.N && p.inv_l != nullptr && fa.hi == 0) p.inv_l[((int64_t)b * p.H + h) * p.N + i] = DYN ? inv * __builtin_amdgcn_exp2f(-c2row) : inv;
+  // saved for the backward in the GLOBAL shift convention; DYN: log2(1 / sum_j exp(S_ij)) = log2(inv) - (row max), which is what
+  // the backward kernels seed their S accumulators with -- the normaliser itself may not fit f32 at such logit ranges
+  if (i < p.N && p.inv_l != nullptr && fa.hi == 0)
+    p.inv_l[((int64_t)b * p.H + h) * p.N + i] = DYN ? __builtin_amdgcn_logf(inv) - c2row : inv;
   // O rows through the LDS (RowEpilogue): every wave issued its last LDS read of the key loop before the final barrier, so the
   // staging buffers are free; the next pass's prologue must not overwrite the scratch while another wave still reads it.
-  have_qpre = false;
-  if (FCSA_FWD_QPRE && pass + 1 < npass) {      // (causal pair: the second row tile is pt)
-    const int ln = opaque(lane);
-    request_q_rows<T, D>(p, b, h, pt * BM + wave * 32 + (ln & 31), ln >> 5, qpre);
-    have_qpre = true;
-  }
   {
     typedef RowEpilogue<T, D> EP;
     if (p.N - mw > 0)
@@ -976,9 +956,6 @@ __global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
 // its 256-row diagonal granularity costs more than the halved LDS traffic saves (N = 4096: -6%, N = 1024: -20%).
 template <int D>
 static bool use_wide_fwd(const FwdParams& p) {
-#ifdef FCSA_FORCE_NARROW_FWD      // A/B measurement builds only
-  return false;
-#endif
   const int MT = (p.N + 255) / 256;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
   if (wgs < 224) return false;

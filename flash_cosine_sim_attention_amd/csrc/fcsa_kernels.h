@@ -14,7 +14,7 @@ struct View {
 
 struct FwdParams {
   View q, k, v, o;          // q,k: already normalised (or raw when !l2norm)
-  float* inv_l;             // [B,H,N] or nullptr
+  float* inv_l;             // [B,H,N] or nullptr; dyn: log2(1 / sum_j exp(S_ij)), else 1 / max(rowsum, l_eps)
   const uint8_t* mask;      // [B,M] or nullptr
   const char* bias;         // [Hb,N,M] contiguous, element type = dtype, or nullptr
   int B, H, N, M;
@@ -27,7 +27,7 @@ struct FwdParams {
   int dyn;                  // 1: per-row exponent shift (row max found by a first pass over K); c2 is 0 then
   int q_raw;                // 1 (16-bit types, fusable groups): q is the RAW query; the kernel prologue does its grouped l2norm,
                             //    folds c1 in, and publishes the saved state of the backward:
-  char* qn_out;             //    [B,H,N,D] contiguous c1 * q^ (dtype)
+  char* qn_out;             //    [B,H,N,D] contiguous c1 * q^ (dtype), or nullptr when no backward follows
   float* rq_out;            //    [B,H,N,G] 1 / max(||q_group||, eps), or nullptr when no backward follows
   int G, lgm;               //    groups; log2(group size / 8)
   float norm_eps;
@@ -41,11 +41,12 @@ struct BwdParams {
   View dq;                  // [B,H,N,D]  dtype, or f32 slab when dq_f32
   View dk, dv;              // [B,H,M,D]  (per q-head!) dtype or f32 slabs
   int dq_f32, dk_f32, dv_f32;   // element type of the gradient outputs above: 1 = float32
-  const float* inv_l;       // [B,H,N]
+  const float* inv_l;       // [B,H,N]: 1 / rowsum, or log2 of it (invl_log2: the forward ran its per-row-shift form)
+  int invl_log2;
   float* delta;             // [B,H,N] scratch: written by the dq kernel, read by the dkv kernel
   const uint8_t* mask;
   const char* bias;
-  float* d_bias;            // [Hb,N,M] f32 zero-initialised or nullptr
+  void* d_bias;             // [Hb,N,M] in the bias dtype, written once per element by bwd_dbias_kernel, or nullptr
   int dq_splits;            // > 1: the dQ kernel splits the KEY range over gridDim.y workgroups that write partial f32 slabs
   int64_t dq_split_stride;  //      byte distance between the slabs of consecutive splits (dq then views slab 0)
   int B, H, N, M;

@@ -14,6 +14,8 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <chrono>
 #include <tuple>
 
 #include "../../include/fcsa.h"
@@ -28,11 +30,25 @@ struct Abi {
   int (*backward)(const fcsa_backward_args*) = &fcsa_backward;
   size_t (*forward_ws)(const fcsa_problem*) = &fcsa_forward_workspace_bytes;
   size_t (*backward_ws)(const fcsa_problem*) = &fcsa_backward_workspace_bytes;
+  int (*needs_qn)(const fcsa_problem*, int32_t) = &fcsa_forward_needs_qn;
   const char* (*last_error)(void) = &fcsa_last_error;
 } g_abi;
 
 using at::Tensor;
 using c10::optional;
+
+// Host-time accounting of the two ops (tools/host_overhead.py; small problems are bound by host time per call, not by the
+// kernels): nanoseconds spent in [0] forward checks / canonicalisation, [1] forward allocations, [2] fcsa_forward (validation +
+// launches), [3..5] the same for backward, [6] forward calls, [7] backward calls.  Two clock reads per section, always on.
+std::atomic<uint64_t> g_host_ns[8];
+struct Lap {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(int slot) {
+    const auto n = std::chrono::steady_clock::now();
+    g_host_ns[slot].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(), std::memory_order_relaxed);
+    t = n;
+  }
+};
 
 int dtype_code(at::ScalarType t) {
   switch (t) {
@@ -144,30 +160,34 @@ void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> forward(const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask,
                                                                     const optional<Tensor>& attn_bias, bool attn_bias_batch_dim, double scale,
                                                                     bool causal, bool l2norm_qk, int64_t groups, bool need_backward) {
+  Lap lap;
   const Canon c = canonicalise(q, k, v, mask, attn_bias, attn_bias_batch_dim, causal);
   TORCH_CHECK_VALUE(!l2norm_qk || (groups >= 1 && c.D % groups == 0), "groups (", groups, ") must divide the head dimension (", c.D, ")");
   c10::DeviceGuard guard(q.device());
+  lap.mark(0);
   const auto opt = q.options();
   const auto f32 = opt.dtype(at::kFloat);
+  fcsa_forward_args a;
+  a.p = problem(c, q.scalar_type(), causal, l2norm_qk, groups, scale);
   Tensor o = at::empty({c.B, c.H, c.N, c.D}, opt);
   Tensor none = at::empty({0}, f32);
   Tensor inv_l = need_backward ? at::empty({c.B, c.H, c.N}, f32) : none;
   Tensor qn = at::empty({0}, opt), kn = qn, rq = none, rk = none;
   if (l2norm_qk) {
-    qn = at::empty({c.B, c.H, c.N, c.D}, opt);
+    // An inference call (need_backward false) gets kn only -- and qn where q takes the row kernel (fcsa_forward_needs_qn): the
+    // 16-bit forward kernels then write nothing but `o` (the reference's need_store_rowsum == false path, cu:1086, cu:1241).
+    if (g_abi.needs_qn(&a.p, need_backward ? 1 : 0) != 0) qn = at::empty({c.B, c.H, c.N, c.D}, opt);
     kn = at::empty({c.B, c.Hk, c.M, c.D}, opt);
     if (need_backward) {
       rq = at::empty({c.B, c.H, c.N, groups}, f32);
       rk = at::empty({c.B, c.Hk, c.M, groups}, f32);
     }
   }
-  fcsa_forward_args a;
-  a.p = problem(c, q.scalar_type(), causal, l2norm_qk, groups, scale);
   a.q = view4(c.q); a.k = view4(c.k); a.v = view4(c.v); a.o = view4(o);
   a.inv_l = need_backward ? inv_l.data_ptr<float>() : nullptr;
   a.mask = c.mask.has_value() ? static_cast<const uint8_t*>(c.mask->data_ptr()) : nullptr;
   a.attn_bias = c.bias.has_value() ? c.bias->data_ptr() : nullptr;
-  a.norm.qn = l2norm_qk ? qn.data_ptr() : nullptr;
+  a.norm.qn = qn.numel() > 0 ? qn.data_ptr() : nullptr;
   a.norm.kn = l2norm_qk ? kn.data_ptr() : nullptr;
   a.norm.rq = (l2norm_qk && need_backward) ? rq.data_ptr<float>() : nullptr;
   a.norm.rk = (l2norm_qk && need_backward) ? rk.data_ptr<float>() : nullptr;
@@ -181,7 +201,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> forward(const Tensor&
     }
   }
   a.stream = stream_of(q);
+  lap.mark(1);
   check(g_abi.forward(&a), "fcsa_forward");
+  lap.mark(2);
+  g_host_ns[6].fetch_add(1, std::memory_order_relaxed);
   if (c.merged) o = o.squeeze(1);                                                                                  // cu:1740-1741
   return std::make_tuple(o, inv_l, qn, kn, rq, rk);
 }
@@ -192,6 +215,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> backward(const Tensor& d_out, const T
                                                     const Tensor& qn, const Tensor& kn, const Tensor& rq, const Tensor& rk,
                                                     bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk, int64_t groups,
                                                     bool need_bias_grad) {
+  Lap lap;
   const Canon c = canonicalise(q, k, v, mask, attn_bias, attn_bias_batch_dim, causal);
   c10::DeviceGuard guard(q.device());
   const auto opt = q.options();
@@ -200,12 +224,27 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> backward(const Tensor& d_out, const T
   if (do4.scalar_type() != q.scalar_type()) do4 = do4.to(q.scalar_type());
   do4 = prep(do4);
   TORCH_CHECK_VALUE(do4.sizes() == o4.sizes(), "d_out must have the shape of the output");
-  TORCH_CHECK_VALUE(inv_l.numel() == c.B * c.H * c.N, "inv_l does not belong to these inputs");
+  TORCH_CHECK_VALUE(o4.size(0) == c.B && o4.size(1) == c.H && o4.size(2) == c.N && o4.size(3) == c.D, "o does not belong to these inputs");
+  // this op is public (torch.ops.fcsa.backward, ext.backward): everything a kernel dereferences is checked, not only its size
+  auto saved_ok = [&](const char* name, const Tensor& t, at::ScalarType st, int64_t numel) {
+    TORCH_CHECK_VALUE(t.defined() && t.device() == q.device() && t.scalar_type() == st && t.numel() == numel && t.is_contiguous(),
+                      name, " does not belong to these inputs (expected a contiguous ", st, " tensor of ", numel, " elements on ", q.device(), ")");
+  };
+  TORCH_CHECK_TYPE(o4.scalar_type() == q.scalar_type() && o4.device() == q.device(), "o must have the dtype and device of q");
+  TORCH_CHECK_VALUE(do4.device() == q.device(), "d_out is on ", do4.device(), " but q is on ", q.device());
+  saved_ok("inv_l", inv_l, at::kFloat, c.B * c.H * c.N);
+  if (l2norm_qk) {
+    saved_ok("qn", qn, q.scalar_type(), c.B * c.H * c.N * c.D);
+    saved_ok("kn", kn, q.scalar_type(), c.B * c.Hk * c.M * c.D);
+    saved_ok("rq", rq, at::kFloat, c.B * c.H * c.N * groups);
+    saved_ok("rk", rk, at::kFloat, c.B * c.Hk * c.M * groups);
+  }
+  lap.mark(3);
   Tensor dq = at::empty({c.B, c.H, c.N, c.D}, opt);
   Tensor dk = at::empty({c.B, c.Hk, c.M, c.D}, opt);
   Tensor dv = at::empty({c.B, c.Hk, c.M, c.D}, opt);
-  Tensor db32;
-  if (c.bias.has_value() && need_bias_grad) db32 = at::zeros(c.bias->sizes(), opt.dtype(at::kFloat));               // cu:1827
+  // d_bias in the bias dtype, every element written once by the library: no zero-fill, no f32 tensor, no cast pass (cf. cu:1827, cu:1912)
+  Tensor db = (c.bias.has_value() && need_bias_grad) ? at::empty(c.bias->sizes(), opt) : at::empty({0}, opt);
   fcsa_backward_args a;
   a.p = problem(c, q.scalar_type(), causal, l2norm_qk, groups, scale);
   size_t wsb = g_abi.backward_ws(&a.p);
@@ -221,11 +260,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> backward(const Tensor& d_out, const T
   a.norm.rq = l2norm_qk ? rq.data_ptr<float>() : nullptr;
   a.norm.rk = l2norm_qk ? rk.data_ptr<float>() : nullptr;
   a.dq = view4(dq); a.dk = view4(dk); a.dv = view4(dv);
-  a.d_bias = db32.defined() ? db32.data_ptr<float>() : nullptr;
+  a.d_bias = db.numel() > 0 ? db.data_ptr() : nullptr;
   a.workspace = ws.data_ptr(); a.workspace_bytes = wsb;
   a.stream = stream_of(q);
+  lap.mark(4);
   check(g_abi.backward(&a), "fcsa_backward");
-  Tensor db = db32.defined() ? db32.to(q.scalar_type()) : at::empty({0}, opt);                                       // cu:1912
+  lap.mark(5);
+  g_host_ns[7].fetch_add(1, std::memory_order_relaxed);
   return std::make_tuple(dq.reshape(q.sizes()), dk.reshape(k.sizes()), dv.reshape(v.sizes()), db);
 }
 
@@ -239,8 +280,8 @@ struct AttentionFn : public torch::autograd::Function<AttentionFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask,
                         const optional<Tensor>& attn_bias, bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk,
                         int64_t groups) {
-    const bool bias_grad = attn_bias.has_value() && attn_bias->requires_grad();
-    const bool need = q.requires_grad() || k.requires_grad() || v.requires_grad() || bias_grad;                    // cu:1689
+    const bool bias_grad = at::GradMode::is_enabled() && attn_bias.has_value() && attn_bias->requires_grad();
+    const bool need = at::GradMode::is_enabled() && (q.requires_grad() || k.requires_grad() || v.requires_grad() || bias_grad);   // cu:1689
     at::AutoDispatchBelowADInplaceOrView guard;
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("fcsa::forward", "")
         .typed<std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const optional<Tensor>&,
@@ -289,6 +330,11 @@ Tensor attention_plain(const Tensor& q, const Tensor& k, const Tensor& v, const 
 
 }  // namespace
 
+// Measurement hook: read (and reset) the host-time counters above.
+extern "C" void fcsa_torch_host_ns(uint64_t* out8) {
+  for (int i = 0; i < 8; ++i) out8[i] = g_host_ns[i].exchange(0, std::memory_order_relaxed);
+}
+
 // Measurement hook (not part of the operator surface): route the ops to another build of libfcsa_hip.so.  Returns 0 on success.
 extern "C" int fcsa_torch_use_library(const char* path) {
   void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -298,8 +344,9 @@ extern "C" int fcsa_torch_use_library(const char* path) {
   a.backward = reinterpret_cast<decltype(a.backward)>(dlsym(h, "fcsa_backward"));
   a.forward_ws = reinterpret_cast<decltype(a.forward_ws)>(dlsym(h, "fcsa_forward_workspace_bytes"));
   a.backward_ws = reinterpret_cast<decltype(a.backward_ws)>(dlsym(h, "fcsa_backward_workspace_bytes"));
+  a.needs_qn = reinterpret_cast<decltype(a.needs_qn)>(dlsym(h, "fcsa_forward_needs_qn"));
   a.last_error = reinterpret_cast<decltype(a.last_error)>(dlsym(h, "fcsa_last_error"));
-  if (!a.forward || !a.backward || !a.forward_ws || !a.backward_ws || !a.last_error) return -2;
+  if (!a.forward || !a.backward || !a.forward_ws || !a.backward_ws || !a.needs_qn || !a.last_error) return -2;
   g_abi = a;
   return 0;
 }

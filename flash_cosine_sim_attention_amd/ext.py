@@ -17,14 +17,17 @@ import ctypes as C
 
 import torch
 
-from . import _core, _lib
+from . import _lib, _torch_ops
 
 
 def forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal):
+    if not q.is_cuda:
+        raise RuntimeError("flash_cosine_sim_attention_amd: q, k, v must be GPU tensors (HIP kernels only, no CPU fallback)")
     should_backwards = any(t is not None and t.requires_grad for t in (q, k, v, attn_bias))       # cu:1689
-    o, saved = _core.attention_forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal,
-                                       l2norm_qk=False, groups=1, need_backward=should_backwards)
-    inv_l = saved.inv_l if saved is not None else torch.empty((q.shape[0], 0), device=q.device, dtype=torch.float32)
+    o, inv_l, _, _, _, _ = _torch_ops.load().forward(q, k, v, mask, attn_bias, bool(attn_bias_batch_dim), float(scale), bool(causal),
+                                                     False, 1, should_backwards)
+    if not should_backwards:
+        inv_l = torch.empty((q.shape[0], 0), device=q.device, dtype=torch.float32)
     # merged batch-heads (q.dim() == 3): inv_l stays [BH, 1, N]; the reference keeps the unsqueezed head dim too (cu:1698)
     return o, inv_l, should_backwards
 
@@ -32,9 +35,10 @@ def forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal):
 def backward(d_out, o, inv_l, q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal):
     empty = q.new_empty((0,))
     empty32 = q.new_empty((0,), dtype=torch.float32)
-    saved = _core.Saved(o, inv_l, q, k, v, mask, attn_bias, empty, empty, empty32, empty32, float(scale), 1, bool(causal), False,
-                        bool(attn_bias_batch_dim))
-    return _core.attention_backward(d_out, saved, need_bias_grad=attn_bias is not None)
+    want_db = attn_bias is not None
+    dq, dk, dv, db = _torch_ops.load().backward(d_out, o, inv_l.contiguous(), q, k, v, mask, attn_bias, empty, empty, empty32, empty32,
+                                                bool(attn_bias_batch_dim), float(scale), bool(causal), False, 1, want_db)
+    return dq, dk, dv, (db if want_db else None)
 
 
 def debug():
@@ -43,3 +47,19 @@ def debug():
     buf = C.create_string_buffer(512)
     lib.fcsa_debug(buf, 512)
     return buf.value.decode()
+
+
+def l2norm_device(t: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """Grouped l2norm of a GPU tensor with the library's row kernel (the C entry point fcsa_l2norm, include/fcsa.h)."""
+    lib = _lib.load()
+    shape = t.shape
+    D = shape[-1]
+    t4 = t.reshape(1, 1, -1, D) if t.dim() < 4 else t.reshape(-1, shape[-3], shape[-2], D)
+    if t4.stride(-1) != 1 or t4.data_ptr() % 16 or any(s % (16 // t4.element_size()) for s in t4.stride()[:-1]):
+        t4 = t4.contiguous()
+    out = torch.empty(t4.shape, device=t.device, dtype=t.dtype)
+    with torch.cuda.device(t.device):
+        x = _lib.tensor4(t4)
+        _lib.check(lib.fcsa_l2norm(_lib.dtype_code(t.dtype), t4.shape[0], t4.shape[1], t4.shape[2], D, groups, C.byref(x), out.data_ptr(),
+                                   None, torch.cuda.current_stream(t.device).cuda_stream), "fcsa_l2norm")
+    return out.reshape(shape)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FCSA_ABI_VERSION 2
+#define FCSA_ABI_VERSION 3
 
 enum fcsa_status {
   FCSA_OK = 0,
@@ -84,12 +84,14 @@ typedef struct fcsa_problem {
                                (exactly the reference extension's contract) */
   int32_t groups;           /* l2norm groups (flash_cosine_sim_attention.py:50-55); 1 if !l2norm_qk */
   float   scale;            /* logits = scale * qh.kh ; reference exponent shift = -scale (cu:1216).
-                               With l2norm_qk the logit range is +-scale*groups.  scale*groups must be <= 87
-                               (FCSA_ERR_UNSUPPORTED beyond: exp of the range leaves float32).  Where no constant
-                               shift fits the range into the exponent of the type P is rounded to (float16:
-                               scale*groups > 11, else > 60) the forward kernel shifts every row by its own max logit
-                               and normalises it exactly (no 1e-10 clamp: in exp(S - scale) units that clamp would
-                               attenuate or zero rows there; the reference kernel itself overflows / zeroes) */
+                               With l2norm_qk the logit range is +-|scale|*groups.  Where no constant shift fits that
+                               range into the exponent of the type P is rounded to (float16: |scale|*groups > 11, else
+                               > 60) the forward kernel shifts every row by its own max logit, normalises it exactly (no
+                               1e-10 clamp: in exp(S - scale) units that clamp would attenuate or zero rows there; the
+                               reference kernel itself overflows / zeroes) and saves log2 of the normaliser instead of
+                               the normaliser, so any finite scale the public signature admits runs
+                               (flash_cosine_sim_attention.py:308-319 has no limit).  Only float16 with
+                               |scale| * log2(e) > 60000 is refused: the folded c1 * q^ would leave the type. */
 } fcsa_problem;
 
 /* State the fused-l2norm forward saves for backward (all caller-allocated, contiguous):
@@ -98,7 +100,7 @@ typedef struct fcsa_problem {
  *   rq [B,H,N,G], rk [B,Hk,M,G] float32     : 1 / max(||x_group||, 1e-12)
  * Unused (may be NULL) when l2norm_qk == 0. */
 typedef struct fcsa_norm_state {
-  void*  qn;
+  void*  qn;                /* may be NULL in a forward call when fcsa_forward_needs_qn() says 0 (inference path) */
   void*  kn;
   float* rq;
   float* rk;
@@ -109,7 +111,8 @@ typedef struct fcsa_forward_args {
   fcsa_tensor     q, k, v;       /* inputs (borrowed, never written) */
   fcsa_tensor     o;             /* output [B,H,N,D] */
   float*          inv_l;         /* [B,H,N] contiguous, or NULL when no backward will follow
-                                    (reference: need_store_rowsum, cu:1086, cu:1241) */
+                                    (reference: need_store_rowsum, cu:1086, cu:1241).  Opaque to the caller: 1 / rowsum,
+                                    or log2 of it in the per-row-shift regime (see `scale`) */
   const uint8_t*  mask;          /* [B,M] contiguous or NULL */
   const void*     attn_bias;     /* [Hb,N,M] contiguous or NULL */
   fcsa_norm_state norm;
@@ -133,11 +136,11 @@ typedef struct fcsa_backward_args {
   fcsa_norm_state norm;          /* from forward (l2norm_qk only) */
   fcsa_tensor     dq;            /* [B,H,N,D]  out */
   fcsa_tensor     dk, dv;        /* [B,Hk,M,D] out */
-  float*          d_bias;        /* [Hb,N,M] float32 or NULL.  Every element is WRITTEN exactly once, deterministically: the
-                                    d_bias kernel recomputes the dS tiles of a bias slice and sums the broadcast index
-                                    (batch or heads) in registers (reference: f32 atomicAdd per element into a zeroed
-                                    tensor, cu:1574-1576; cast at cu:1912).  Zero-initialising it, as the reference's
-                                    caller does, is harmless and not required. */
+  void*           d_bias;        /* [Hb,N,M] in `dtype` (the dtype the reference returns it in, cu:1912) or NULL.  Every
+                                    element is WRITTEN exactly once, deterministically: the d_bias kernel recomputes the dS
+                                    tiles of a bias slice, sums the broadcast index (batch or heads) in float32 registers
+                                    and rounds once (reference: f32 atomicAdd per element into a zeroed f32 tensor,
+                                    cu:1574-1576, then a cast pass, cu:1912).  No zero-fill, no cast needed. */
   void*           workspace;     /* >= fcsa_backward_workspace_bytes(&p) bytes, 256-byte aligned */
   size_t          workspace_bytes;
   void*           stream;
@@ -156,6 +159,12 @@ size_t fcsa_backward_workspace_bytes(const fcsa_problem* p);
 
 /* Bytes of optional forward scratch that enable the split-key forward for this problem (0: never split). */
 size_t fcsa_forward_workspace_bytes(const fcsa_problem* p);
+
+/* 1 if fcsa_forward needs the norm.qn buffer for this problem, else 0.  It always does when a backward follows
+ * (`need_backward`: qn is saved state) or l2norm_qk is off (unused then); an inference call needs it only where q is
+ * normalised by the row kernel (float32, or group sizes that are not 8 * 2^k features) -- the 16-bit forward kernels
+ * normalise q in registers and then write NOTHING but `o` (the reference's need_store_rowsum == false path, cu:1086). */
+int fcsa_forward_needs_qn(const fcsa_problem* p, int32_t need_backward);
 
 /* Standalone grouped l2norm on device: the public l2norm_tensors (flash_cosine_sim_attention.py:57-65).
  * x [B,H,N,D] (strided) -> xn [B,H,N,D] contiguous, inv_norm [B,H,N,G] float32 (may be NULL). */

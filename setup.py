@@ -9,6 +9,7 @@ hipified, there is no CUDA path.
 """
 import os
 import subprocess
+import sys
 
 from setuptools import setup
 from setuptools.command.build_py import build_py
@@ -18,7 +19,10 @@ PKG = "flash_cosine_sim_attention_amd"
 
 
 def build_native():
-    subprocess.check_call(["make", "-C", os.path.join(HERE, PKG, "csrc"), "-j", str(min(8, os.cpu_count() or 1))])
+    # PYTHON: the binding must compile and link against the torch of the interpreter that runs this build (and will import the
+    # package), not whatever `python3` is first on PATH.  Build with `pip install --no-build-isolation .` so that this IS the
+    # ROCm torch of the environment (an isolated build env would pull a different torch wheel).
+    subprocess.check_call(["make", "-C", os.path.join(HERE, PKG, "csrc"), "-j", str(min(8, os.cpu_count() or 1)), "PYTHON=" + sys.executable])
 
 
 class BuildWithNative(build_py):
@@ -39,7 +43,7 @@ except ImportError:      # pragma: no cover
 
 setup(
     name="flash-cosine-sim-attention-amd",
-    version="0.2.0",
+    version="0.3.0",
     description="Fused cosine-similarity attention for AMD MI355X (gfx950): hand-written HIP kernels behind the "
                 "flash_cosine_sim_attention(q, k, v, ...) API",
     packages=[PKG],

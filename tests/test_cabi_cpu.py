@@ -125,6 +125,41 @@ def test_backward_workspace_formula(lib):
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + 2 * al(B * H * M * D * 4)
 
 
+def test_backward_workspace_single_head_non_causal_stays_small(lib):
+    """the dQ slab is sized by the SAME split rule the launch uses (batch * heads row tiles), so a heads == 1 problem
+    whose grid already fills the chip needs only the delta workspace (it used to reserve dq_splits x f32 dQ: 1 GiB here)."""
+    al = lambda x: (x + 255) // 256 * 256
+    p = _problem(batch=64, heads=1, kv_heads=1, q_len=8192, k_len=8192, dim_head=128, dtype=2, l2norm_qk=1)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(64 * 8192 * 4)
+    p = _problem(batch=64, heads=1, kv_heads=1, q_len=8192, k_len=8192, dim_head=128, dtype=2, l2norm_qk=1, bias_batch_dim=1)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(64 * 8192 * 4)
+    # a grid that cannot fill the chip still gets its split slabs: C4 = 8 heads x 8 row tiles of 128 -> 4 splits
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64, dtype=1, l2norm_qk=1)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 1024 * 4) + al(4 * 8 * 1024 * 64 * 4)
+
+
+def test_forward_needs_qn(lib):
+    """Inference calls of the 16-bit kernels save no normalised q (the reference's need_store_rowsum == false path, cu:1086)."""
+    f = lambda need, **kw: lib.fcsa_forward_needs_qn(C.byref(_problem(l2norm_qk=1, **kw)), need)
+    assert f(1, dtype=2) == 1 and f(0, dtype=2) == 0 and f(0, dtype=1, groups=8) == 0
+    assert f(0, dtype=0) == 1                              # float32: q goes through the row kernel
+    assert f(0, dtype=2, dim_head=96, groups=8) == 1       # group size 12: row kernel
+    assert lib.fcsa_forward_needs_qn(C.byref(_problem(l2norm_qk=0)), 1) == 0
+    assert lib.fcsa_forward_needs_qn(None, 1) == 0
+
+
+def test_scale_range(lib):
+    """No scale * groups limit any more (the public signature has none, py:308-319); only f16 refuses a scale whose folded
+    c1 = scale * log2(e) leaves the type, and non-finite scales are invalid."""
+    # (validation order: problem first, then buffers -- the NULL norm.kn of _fwd_args stops the call before any launch)
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(l2norm_qk=1, groups=8, scale=16.0, dtype=2))))
+    assert rc == -1 and b"norm.kn" in lib.fcsa_last_error()              # scale * groups = 128 passed the problem check
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(l2norm_qk=1, scale=50000.0, dtype=1))))
+    assert rc == -2 and b"float16" in lib.fcsa_last_error()
+    rc = lib.fcsa_forward(C.byref(_fwd_args(_problem(l2norm_qk=1, scale=float("inf")))))
+    assert rc == -1 and b"scale" in lib.fcsa_last_error()
+
+
 def test_forward_workspace_formula(lib):
     # split-key forward: only non-causal problems whose 128-row tiles cannot fill the chip, with >= 1024 keys
     al = lambda x: (x + 255) // 256 * 256
@@ -141,7 +176,8 @@ def test_forward_workspace_formula(lib):
 
 def test_debug_string(lib):
     buf = C.create_string_buffer(512)
-    assert lib.fcsa_debug(buf, 512) == 2          # FCSA_ABI_VERSION
+    from flash_cosine_sim_attention_amd import _lib
+    assert lib.fcsa_debug(buf, 512) == _lib.ABI_VERSION == 3          # FCSA_ABI_VERSION (include/fcsa.h)
     assert b"gfx950" in buf.value and b"bf16" in buf.value
 
 
@@ -149,10 +185,10 @@ def test_gpu_entry_points_reject_cpu_tensors():
     """The HIP path never falls back: the C-ABI glue refuses host tensors (CPU tensors are served by the operator's own
     forward-only host path instead, see tests/test_cpu_path.py)."""
     import torch
-    from flash_cosine_sim_attention_amd import _core, ops
+    from flash_cosine_sim_attention_amd import ext, ops
     q = torch.randn(1, 2, 8, 64)
     with pytest.raises(RuntimeError, match="GPU"):
-        _core.attention_forward(q, q, q)
+        ext.forward(q, q, q, None, None, False, 8.0, False)
     with pytest.raises(RuntimeError, match="GPU"):
         ops.flash_cosine_sim_attention_hip(q, q, q, None, None, 8, 1, False, True, False)
 

@@ -18,7 +18,7 @@ def test_fcsa_l2norm_entry_vs_oracle(dtype, d, groups):
     """fcsa_l2norm (the public l2norm_tensors as a C entry point): xn and the saved inverse norms, incl. group sizes that are
     not 8 * 2^k (96 / 4 = 24, 96 / 3 = 32, 48 / 3 = 16) and a strided input view."""
     import ctypes as C
-    from flash_cosine_sim_attention_amd import _core, _lib
+    from flash_cosine_sim_attention_amd import ext, _lib
     from oracle import cosine_sim_oracle as O
     lib = _lib.load()
     torch.manual_seed(d + groups)
@@ -27,7 +27,7 @@ def test_fcsa_l2norm_entry_vs_oracle(dtype, d, groups):
     out = torch.empty((2, 3, 37, d), device="cuda", dtype=dtype)
     inv = torch.empty((2, 3, 37, groups), device="cuda", dtype=torch.float32)
     t = _lib.Tensor(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2))
-    rc = lib.fcsa_l2norm(_core._DTYPES[dtype], 2, 3, 37, d, groups, C.byref(t), out.data_ptr(), inv.data_ptr(),
+    rc = lib.fcsa_l2norm(_lib.dtype_code(dtype), 2, 3, 37, d, groups, C.byref(t), out.data_ptr(), inv.data_ptr(),
                          torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.fcsa_last_error()
     xd = x.double().cpu().numpy()
@@ -37,7 +37,7 @@ def test_fcsa_l2norm_entry_vs_oracle(dtype, d, groups):
     norms = np.linalg.norm(xd.reshape(2, 3, 37, groups, d // groups), axis=-1)
     assert np.abs(inv.double().cpu().numpy() * norms - 1).max() <= 1e-5
     # the Python helper over the same entry point
-    assert torch.equal(_core.l2norm_device(x.contiguous(), groups), out)
+    assert torch.equal(ext.l2norm_device(x.contiguous(), groups), out)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")

@@ -278,6 +278,15 @@ def test_no_grad_path_skips_saved_state():
     with torch.no_grad():
         o = F.flash_cosine_sim_attention(q, q, q, causal=True)
     assert not o.requires_grad and torch.isfinite(o).all()
+    # inputs that require grad, under no_grad: still the inference path -- nothing saved, same output
+    qg = q.clone().requires_grad_()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        o2 = F.flash_cosine_sim_attention(qg, qg, qg, causal=True)
+    assert not o2.requires_grad and o2.grad_fn is None and torch.equal(o2, o)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() - base <= o2.numel() * o2.element_size() + 4096      # only `o` outlives the call
 
 
 def test_hip_at_least_as_accurate_as_pytorch_same_dtype():

@@ -34,9 +34,9 @@ def _npf(t):
 @pytest.mark.parametrize("dtype,B,H,N,M,D,use_mask,single_kv,l2norm,groups", CASES)
 def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups):
     import flash_cosine_sim_attention_amd as F
-    from flash_cosine_sim_attention_amd import _core, _lib
+    from flash_cosine_sim_attention_amd import _lib
     dt = DT[dtype]
-    prob = _core._problem(dt, (B, H, 1 if single_kv else H, N, M, D), False, False, l2norm, groups, 8.0 if l2norm else 0.125)
+    prob = _lib.problem(dt, (B, H, 1 if single_kv else H, N, M, D), False, False, l2norm, groups, 8.0 if l2norm else 0.125)
     assert _lib.load().fcsa_forward_workspace_bytes(C.byref(prob)) > 0, "case would not take the split-key path"
     g = torch.Generator(device="cuda").manual_seed(N * 7 + M)
     q = torch.randn((B, H, N, D), device="cuda", dtype=dt, generator=g)
@@ -70,7 +70,7 @@ def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv,
 
 def test_split_and_unsplit_agree_through_the_c_abi():
     """Same problem with and without the optional workspace: the C ABI promises the same result."""
-    from flash_cosine_sim_attention_amd import _core, _lib
+    from flash_cosine_sim_attention_amd import _lib
     lib = _lib.load()
     B, H, N, M, D = 1, 4, 96, 3000, 64
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -80,11 +80,11 @@ def test_split_and_unsplit_agree_through_the_c_abi():
         o = torch.empty_like(q)
         inv_l = torch.empty((B, H, N), device="cuda", dtype=torch.float32)
         qn, kn = torch.empty_like(q), torch.empty_like(k)
-        prob = _core._problem(q.dtype, (B, H, H, N, M, D), False, False, True, 1, 8.0)
+        prob = _lib.problem(q.dtype, (B, H, H, N, M, D), False, False, True, 1, 8.0)
         nbytes = int(lib.fcsa_forward_workspace_bytes(C.byref(prob)))
         assert nbytes > 0
         ws = torch.empty((nbytes,), device="cuda", dtype=torch.uint8) if use_ws else None
-        args = _lib.ForwardArgs(prob, _core._tensor4(q), _core._tensor4(k), _core._tensor4(v), _core._tensor4(o), inv_l.data_ptr(),
+        args = _lib.ForwardArgs(prob, _lib.tensor4(q), _lib.tensor4(k), _lib.tensor4(v), _lib.tensor4(o), inv_l.data_ptr(),
                                 None, None, _lib.NormState(qn.data_ptr(), kn.data_ptr(), None, None),
                                 None if ws is None else ws.data_ptr(), 0 if ws is None else nbytes,
                                 torch.cuda.current_stream().cuda_stream)

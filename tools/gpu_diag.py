@@ -72,11 +72,11 @@ def run(dtype, b, h, n, m, d, causal=False, grads=True, v_mode="rand", seed=0, l
 
 
 def norm_check(dtype, d, groups=1):
-    from flash_cosine_sim_attention_amd import _core
+    from flash_cosine_sim_attention_amd import ext
     torch.manual_seed(5)
     x = torch.randn(2, 3, 37, d, device="cuda", dtype=dtype)
     try:
-        got = _core.l2norm_device(x, groups)
+        got = ext.l2norm_device(x, groups)
         ref = O.l2norm(npf(x), groups)
         P(f"l2norm {dtype} D{d} G{groups}: max-abs {np.abs(npf(got) - ref).max():.3e}")
     except Exception:

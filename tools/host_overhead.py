@@ -27,7 +27,15 @@ bench("flash_cosine_sim_attention, grad (forward only)", lambda: F.flash_cosine_
 def fb():
     q.grad = k.grad = v.grad = None
     F.flash_cosine_sim_attention(q, k, v, causal=True).backward(do)
+import ctypes
+_b = ctypes.CDLL(_torch_ops.BINDING_PATH)
+_cnt = (ctypes.c_uint64 * 8)()
+_b.fcsa_torch_host_ns(_cnt)                    # reset the binding's host-time counters
 bench("forward + backward(dO)", fb)
+_b.fcsa_torch_host_ns(_cnt)
+nf, nb = max(_cnt[6], 1), max(_cnt[7], 1)
+print("   inside the binding, us per call: forward checks %.1f | allocations %.1f | fcsa_forward %.1f || backward checks %.1f | allocations %.1f | fcsa_backward %.1f"
+      % (_cnt[0] / nf / 1e3, _cnt[1] / nf / 1e3, _cnt[2] / nf / 1e3, _cnt[3] / nb / 1e3, _cnt[4] / nb / 1e3, _cnt[5] / nb / 1e3))
 def fbs():
     q.grad = k.grad = v.grad = None
     F.flash_cosine_sim_attention(q, k, v, causal=True).sum().backward()
