@@ -346,7 +346,8 @@ extern "C" int fcsa_torch_use_library(const char* path) {
   a.backward_ws = reinterpret_cast<decltype(a.backward_ws)>(dlsym(h, "fcsa_backward_workspace_bytes"));
   a.needs_qn = reinterpret_cast<decltype(a.needs_qn)>(dlsym(h, "fcsa_forward_needs_qn"));
   a.last_error = reinterpret_cast<decltype(a.last_error)>(dlsym(h, "fcsa_last_error"));
-  if (!a.forward || !a.backward || !a.forward_ws || !a.backward_ws || !a.needs_qn || !a.last_error) return -2;
+  if (!a.needs_qn) a.needs_qn = [](const fcsa_problem*, int32_t) { return 1; };      // ABI 2 builds (A/B against an older library)
+  if (!a.forward || !a.backward || !a.forward_ws || !a.backward_ws || !a.last_error) return -2;
   g_abi = a;
   return 0;
 }

@@ -10,7 +10,9 @@ SHAPES = {
     "d64":   dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.bfloat16, causal=True, groups=1),
     "d128":  dict(q=(4, 8, 4096, 128), kv=(4, 8, 4096, 128), dtype=torch.bfloat16, causal=True, groups=1),
     "d128nc": dict(q=(4, 8, 2048, 128), kv=(4, 8, 2048, 128), dtype=torch.bfloat16, causal=False, groups=1),
-    "C5":    dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, groups=8),
+    "C5":    dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, groups=8, scale=1),
+    "C4":    dict(q=(1, 8, 1024, 64), kv=(1, 8, 8192, 64), dtype=torch.float16, causal=False, groups=1, mask=True),
+    "C5s8":  dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, groups=8, scale=8),
     "d32":   dict(q=(4, 8, 4096, 32), kv=(4, 8, 4096, 32), dtype=torch.bfloat16, causal=True, groups=1),
     "d96":   dict(q=(4, 8, 4096, 96), kv=(4, 8, 4096, 96), dtype=torch.bfloat16, causal=True, groups=1),
     "d64f32": dict(q=(2, 8, 2048, 64), kv=(2, 8, 2048, 64), dtype=torch.float32, causal=True, groups=1),
@@ -25,10 +27,11 @@ for name in sel:
     v = torch.randn(c["kv"], device="cuda", dtype=c["dtype"]).requires_grad_()
     do = torch.randn(c["q"], device="cuda", dtype=c["dtype"])
     bias = torch.randn(c["q"][1], c["q"][2], c["kv"][-2], device="cuda", dtype=c["dtype"]).requires_grad_() if c.get("bias") else None
+    mask = (torch.rand((c["q"][0], c["kv"][-2]), device="cuda") > 0.25) if c.get("mask") else None
     def step():
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=c["causal"], groups=c["groups"]).backward(do)
+        F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=c["causal"], groups=c["groups"], scale=c.get("scale", 8)).backward(do)
     for _ in range(int(os.environ.get("WARM", "5"))): step()
     torch.cuda.synchronize()
     _lib.profile_enable(True)
