@@ -280,8 +280,9 @@ struct AttentionFn : public torch::autograd::Function<AttentionFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask,
                         const optional<Tensor>& attn_bias, bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk,
                         int64_t groups) {
-    const bool bias_grad = at::GradMode::is_enabled() && attn_bias.has_value() && attn_bias->requires_grad();
-    const bool need = at::GradMode::is_enabled() && (q.requires_grad() || k.requires_grad() || v.requires_grad() || bias_grad);   // cu:1689
+    // (Function::apply runs this with grad mode OFF: the no_grad case is decided by the caller, attention_autograd)
+    const bool bias_grad = attn_bias.has_value() && attn_bias->requires_grad();
+    const bool need = q.requires_grad() || k.requires_grad() || v.requires_grad() || bias_grad;                    // cu:1689
     at::AutoDispatchBelowADInplaceOrView guard;
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("fcsa::forward", "")
         .typed<std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const optional<Tensor>&,
@@ -319,6 +320,14 @@ struct AttentionFn : public torch::autograd::Function<AttentionFn> {
 
 Tensor attention_autograd(const Tensor& q, const Tensor& k, const Tensor& v, const optional<Tensor>& mask, const optional<Tensor>& attn_bias,
                           bool attn_bias_batch_dim, double scale, bool causal, bool l2norm_qk, int64_t groups) {
+  // under torch.no_grad() nothing will ever call backward, whatever the inputs' requires_grad says: take the inference path
+  // (no saved state, no inv_l / inverse-norm / normalised-q writes), like a Python Function's ctx.needs_input_grad would
+  const bool tracked = at::GradMode::is_enabled() &&
+                       (q.requires_grad() || k.requires_grad() || v.requires_grad() || (attn_bias.has_value() && attn_bias->requires_grad()));
+  if (!tracked) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    return std::get<0>(forward(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal, l2norm_qk, groups, false));
+  }
   return AttentionFn::apply(q, k, v, mask, attn_bias, attn_bias_batch_dim, scale, causal, l2norm_qk, groups);
 }
 

@@ -26,10 +26,16 @@ _torch_ops.load()
 binding = ctypes.CDLL(_torch_ops.BINDING_PATH)          # same loaded object as the dispatcher ops use
 libs, paths = {}, {}
 pkg = os.path.join(ROOT, "flash_cosine_sim_attention_amd")
+def open_lib(path):
+    """ctypes handle with the profile hooks only (older ABI versions are welcome here: the binding falls back for symbols they lack)"""
+    lib = ctypes.CDLL(path)
+    lib.fcsa_profile_enable.argtypes = [ctypes.c_int32]
+    lib.fcsa_profile_collect.argtypes = [ctypes.POINTER(_lib.KernelStat), ctypes.c_int32]
+    lib.fcsa_last_error.restype = ctypes.c_char_p
+    return lib
 for t in a.tags:
-    _lib._lib = None
-    _lib.LIB_PATH = paths[t] = os.path.join(pkg, "libfcsa_hip.so" if t == "main" else f"libfcsa_hip_{t}.so")
-    libs[t] = _lib.load()                                # ctypes handle of the same object: its profile hooks
+    paths[t] = os.path.join(pkg, "libfcsa_hip.so" if t == "main" else f"libfcsa_hip_{t}.so")
+    libs[t] = open_lib(paths[t])
 res = {t: {} for t in a.tags}
 for r in range(a.rounds + 1):
     for t in a.tags:
