@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDq2WBytes ? 2 
   }
   // geometry of iteration (pass_): row tile, this lane's row, number of 64-key tiles
   auto geometry = [&](int pass_, int& m0_, int& nt_) {
-    const int mt_ = p.causal ? ((pass_ == 0) != FCSA_FLIP(blockIdx.x) ? MT - 1 - pt : pt) : pt;      // heavy tile first
+    const int mt_ = p.causal ? (pass_ == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
     m0_ = mt_ * BM;
     int last_key = Mk - 1;
     if (p.causal) last_key = min(last_key, m0_ + BM - 1 + diff);
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
   };
   // geometry of a pass: first key of the workgroup's key tile, first query tile it needs (causal keeps i >= j - diff)
   auto geometry = [&](int pass_, int& n0_, int& t0_) {
-    const int kt_ = p.causal ? ((pass_ == 0) != FCSA_FLIP(blockIdx.x) ? pt : KT - 1 - pt) : pt;      // heavy tile first
+    const int kt_ = p.causal ? (pass_ == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
     n0_ = kt_ * BNK;
     t0_ = p.causal ? max(0, n0_ - diff) / BMQ : 0;
   };

@@ -92,21 +92,26 @@ fcsa::View contiguous_view(void* p, int64_t heads, int64_t len, int64_t d, int e
 // inv_l carries it, and forward / backward derive it identically from the problem description.
 //   * l2norm_qk == 0 (the reference extension's contract, q,k pre-normalised by the caller): shift = scale,
 //     exactly cu:1216, so inv_l has the reference's values.
-//   * fused l2norm: the logit is bounded by scale * groups.
-//       f16 : shift = scale*groups - 10  ->  P~ <= e^10 = 22026 < 65504, and typical P~ (logit ~ 0) stays in
+//   * fused l2norm: the logit lies in [-bound, +bound], bound = |scale| * groups.
+//       f16 : shift = bound - 10  ->  P~ <= e^10 = 22026 < 65504, and typical P~ (logit ~ 0) stays in
 //             f16's NORMAL range even for large scale (with the reference's shift, scale = 16 puts exp(-16)
 //             = 1e-7 into f16 subnormals and the output error grows 10x).
-//       bf16 / f32 (8-bit exponent): shift = max(scale, scale*groups - 40); equals the reference for groups = 1.
-// A static shift only works while the whole logit range [-scale*groups, +scale*groups] fits the exponent range of the type
-// P~ is rounded to.  Real rows peak far below the theoretical bound once groups > 1 (found by the fuzz test: f16,
-// groups >= 4, scale >= 8 underflowed every P~ of a row to 0; the reference's shift = scale overflows there instead).
+//       bf16 / f32 (8-bit exponent): every P~ must stay a normal f32 and a row sum (up to ~1e5 keys of it) below f32's top:
+//             exp(s - shift) in [e^-85, e^65]  <=>  shift in [bound - 65, 85 - bound], non-empty for bound <= 75.  The shift is
+//             the reference's (= scale) wherever that lies in the interval, else the nearest end.  (Round 2 used
+//             max(scale, bound - 40): the same values for bound <= 42, but it sent 60 < bound <= 75 -- C5 at the default scale 8 --
+//             through the two-pass dynamic form, and it kept the reference's underflow for groups = 1, scale > 42.)
+// A static shift only works while the whole logit range fits the exponent range of the type P~ is rounded to.  Real rows peak
+// far below the theoretical bound once groups > 1 (found by the fuzz test: f16, groups >= 4, scale >= 8 underflowed every P~ of a
+// row to 0; the reference's shift = scale overflows there instead).
 // Beyond the safe range the forward kernel finds each row's max logit first and shifts by that ("dynamic"); what it saves
 // for the backward is then log2(1 / sum_j exp(S_ij)) -- the value the backward kernels seed their S accumulators with anyway --
 // so nothing ever holds exp() of the full logit range and there is no limit on scale * groups.
+constexpr float kStaticTop = 65.f, kStaticBottom = 85.f;      // exp(s - shift) stays within [e^-85, e^65] (bf16 / f32)
 bool dynamic_shift(const fcsa_problem& p) {
   if (!p.l2norm_qk) return false;
   const float bound = fabsf(p.scale) * (float)p.groups;
-  return p.dtype == FCSA_F16 ? bound > 11.f : bound > 60.f;
+  return p.dtype == FCSA_F16 ? bound > 11.f : 2.f * bound > kStaticTop + kStaticBottom;
 }
 
 float exponent_shift(const fcsa_problem& p) {
@@ -114,7 +119,8 @@ float exponent_shift(const fcsa_problem& p) {
   if (dynamic_shift(p)) return 0.f;
   const float bound = fabsf(p.scale) * (float)p.groups;
   if (p.dtype == FCSA_F16) return bound - 10.f;
-  return bound - 40.f > p.scale ? bound - 40.f : p.scale;
+  const float lo = bound - kStaticTop, hi = kStaticBottom - bound;
+  return p.scale < lo ? lo : (p.scale > hi ? hi : p.scale);
 }
 
 // Row-sum clamp: the reference clamps l at 1e-10 (cu:83, cu:1239) with shift = scale; with another shift the

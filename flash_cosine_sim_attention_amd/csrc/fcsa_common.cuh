@@ -40,13 +40,6 @@ typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
 
 #define FCSA_DEV __device__ __forceinline__
-// EXPERIMENT (A/B builds): workgroups with an odd slot on their XCD run their causal tile pair light-first, so that the
-// mid-kernel pass boundary (epilogue write burst + next prologue) of one half of the chip falls into the tile loops of the other
-#ifdef FCSA_EXP_STAGGER
-#define FCSA_FLIP(bid) ((((bid) >> 3) & 1) != 0)
-#else
-#define FCSA_FLIP(bid) false
-#endif
 
 // NOTE: always pass vector ELEMENTS through this by-value helper.  `__builtin_bit_cast(float, v[t])`
 // applied directly to an ext_vector element lvalue is miscompiled by hipcc 7.2 (it reads element 0

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
 #endif
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
-  const int mt = p.causal ? ((pass == 0) != FCSA_FLIP(blockIdx.x) ? MT - 1 - pt : pt) : pt;      // heavy tile first
+  const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;                  // first query row of this wave
   const int i = mw + (lane & 31);                 // this lane's query row
@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
 #endif
 
   for (int pass = 0; pass < npass; ++pass) {
-    const int mt = p.causal ? ((pass == 0) != FCSA_FLIP(blockIdx.x) ? MT - 1 - pt : pt) : pt;      // heavy tile first
+    const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
     const int m0 = mt * BM;
     const int mw = m0 + wave * RW;                  // first query row of this wave
     const int i0 = mw + (lane & 31);                // this lane's row in block 0; block 1 is i0 + 32

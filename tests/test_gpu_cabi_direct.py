@@ -103,7 +103,7 @@ def test_c_abi_forward_backward_vs_oracle(dtype, B, H, Hk, N, M, D, kw):
     # per-row-shift regime: rows are normalised exactly (like the reference's PyTorch path); the oracle's restatement of the
     # reference KERNEL's 1e-10 clamp in exp(S - scale) units would zero rows there (tests/test_gpu_fuzz.py)
     bound = abs(okw["scale"]) * okw["groups"]
-    if okw["l2norm_qk"] and (bound > 11 if dtype == "f16" else bound > 60):
+    if okw["l2norm_qk"] and (bound > 11 if dtype == "f16" else bound > 75):
         okw["eps"] = 1e-300
     ro, _ = O.attention_forward_stats(_np(r["q"]), _np(k_in), _np(v_in), **okw)
     cond = max(1.0, abs(okw["scale"]) * okw["groups"] / 16.0) if dtype != "f32" else 1.0    # logit error grows with the logit range (test_gpu_fuzz.py)

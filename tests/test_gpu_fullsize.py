@@ -43,8 +43,10 @@ def _configs():
         "C3": dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.bfloat16, causal=True, mask=False, scale=8, groups=1),
         "C4": dict(q=(1, 8, 1024, 64), kv=(1, 8, 8192, 64), dtype=torch.float16, causal=False, mask=True, scale=8, groups=1),
         "C5": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, mask=False, scale=1, groups=8),
-        # C5 also at the default scale = 8 -> scale * groups = 64 > 60: the per-row (dynamic) exponent shift forward
+        # C5 also at the default scale = 8 -> scale * groups = 64: since round 3 inside the static exponent window
+        # (bf16: up to 75); "C5s10" below runs the per-row (dynamic) shift forward at full size
         "C5s8": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, mask=False, scale=8, groups=8),
+        "C5s10": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, mask=False, scale=10, groups=8),
     }
 
 
@@ -59,7 +61,7 @@ def _make(cfg, seed=0):
     return q, k, v, mask
 
 
-@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "C5s8"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "C5s8", "C5s10"])
 def test_forward_fullsize_vs_f32_slices_and_identities(name):
     import flash_cosine_sim_attention_amd as F
     cfg = _configs()[name]
@@ -93,7 +95,7 @@ def test_forward_fullsize_vs_f32_slices_and_identities(name):
         assert (op.float() - o.float()).abs().max().item() <= 2 * atol
 
 
-@pytest.mark.parametrize("name", ["C3", "C5", "C4", "C5s8"])
+@pytest.mark.parametrize("name", ["C3", "C5", "C4", "C5s8", "C5s10"])
 def test_backward_fullsize_identities_and_slices(name):
     import flash_cosine_sim_attention_amd as F
     cfg = _configs()[name]

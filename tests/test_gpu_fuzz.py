@@ -94,7 +94,7 @@ def test_random_config_matches_oracle(cfg):
     # plain_cosine_sim_attention; the reference KERNEL's clamp max(l, 1e-10), taken in exp(S - scale) units, attenuates or
     # zeroes rows at such logit ranges (scale 70: every row).  The oracle restates that clamp, so switch it off there.
     bound = cfg["scale"] * cfg["groups"]
-    dyn = cfg["l2norm"] and (bound > 11 if cfg["dtype"] == "f16" else bound > 60)
+    dyn = cfg["l2norm"] and (bound > 11 if cfg["dtype"] == "f16" else bound > 75)      # fcsa_capi.hip dynamic_shift
     eps = 1e-300 if dyn else 1e-10
     atol, rtol = FWD_TOL[cfg["dtype"]]
     cond = max(1.0, cfg["scale"] * cfg["groups"] / 16.0) if cfg["dtype"] != "f32" and cfg["l2norm"] else 1.0
