@@ -183,9 +183,13 @@ FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, co
 
 // LDS plan of the dQ kernel (EpiLds): the next iteration is requested ahead of the epilogue when the stages arrive by LDS-DMA and
 // the scratch fits behind them.
+// K / V stages of the dQ kernel arrive by LDS-DMA for the 16-bit types and for 512-byte rows (f32, D = 128: the staging registers of
+// the register path -- 64 + 16 per lane -- are what pushed that instantiation into scratch)
+template <typename T, int D> constexpr bool dq_dma(int sub) {
+  return (Traits<T>::ES == 2 || D * Traits<T>::ES >= 512) && (64 * sub * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
+}
 template <typename T, int D, int NW, int SUB> struct DqLds
-    : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB,
-             Traits<T>::ES == 2 && (64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+    : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB, dq_dma<T, D>(SUB),
              ((NW == 8 || D * Traits<T>::ES > kDq2WBytes) ? 160 : 80) * 1024> {};
 
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDq2WBytes ? 2 
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
   // K / V stages: LDS-DMA for 16-bit types (no staging registers, no ds_write passes; see DmaStager), else through registers.
-  constexpr bool DMA = TR::ES == 2 && (BNS * G::ROWB) % 1024 == 0;
+  constexpr bool DMA = dq_dma<T, D>(SUB);
   // SEP: the epilogue scratch has its own LDS bytes behind the staging buffers.  Then nothing of one (row tile) iteration has to
   // be finished before the next one starts loading: the first K / V stage and this lane's Q^ / dO / O row chunks of the NEXT
   // iteration are requested before the epilogue of the current one and land while it runs (the pass marks of the WG trace showed
@@ -549,8 +553,12 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDq2WBytes ? 2 
 // and writes the tile once, transposed through the LDS into whole rows: no atomics, no read-modify-write, slices x row tiles x
 // key tiles workgroups, and the dQ kernel runs its plain form.  Needs delta (published by the dQ kernel, launched first).
 // =============================================================================================
+// Registers: two row-fragment sets (current + requested-ahead), two staging sets, 64 bias / sum values -- two waves per SIMD (256
+// registers) only fit rows of <= 128 bytes; wider rows run one wave per SIMD, and 512-byte rows (f32, D = 128) load their row
+// fragments at the top of the iteration instead of one iteration ahead.  (Round 2 asked for 2 waves / SIMD up to 256-byte rows and
+// spilled 60 - 145 registers to scratch there.)
 template <typename T, int D>
-__global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_dbias_kernel(const BwdParams p) {
+__global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 128 ? 2 : 1)) bwd_dbias_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 128, NT = 256;
@@ -601,25 +609,30 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
   sv.init(p.v.sn, tid);
   // everything an iteration reads from global memory is requested one iteration ahead (its K / V tile into the staging registers,
   // this lane's row chunks and per-row terms into n*): the round trip overlaps the previous iteration's tile
-  u32x4 nq[G::KS], ndo[G::KS];
+  constexpr bool ROWS_AHEAD = G::KS < 16;
+  u32x4 nq[ROWS_AHEAD ? G::KS : 1], ndo[ROWS_AHEAD ? G::KS : 1];
   float ninvl = 1.f, ndelta = 0.f;
   uint8_t nmask = 1;
-  auto request = [&](int red_) {
+  auto load_rows = [&](int red_, u32x4* rq, u32x4* rdo) {
     const int b = p.bias_batch ? owner : red_, h = p.bias_batch ? red_ : owner;
-    sk.load(p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j0 * p.k.sn, p.k.sn, p.M - j0);
-    sv.load(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j0 * p.v.sn, p.v.sn, p.M - j0);
     const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
     const char* dorow = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh + (int64_t)i * p.d_out.sn;
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) {
       const u32x4 z = {0u, 0u, 0u, 0u};
-      nq[kk] = z;
-      ndo[kk] = z;
+      rq[kk] = z;
+      rdo[kk] = z;
       if (i < p.N) {
-        nq[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
-        ndo[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
+        rq[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + fa.hi) * 16);
+        rdo[kk] = *reinterpret_cast<const u32x4*>(dorow + (2 * kk + fa.hi) * 16);
       }
     }
+  };
+  auto request = [&](int red_) {
+    const int b = p.bias_batch ? owner : red_, h = p.bias_batch ? red_ : owner;
+    sk.load(p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j0 * p.k.sn, p.k.sn, p.M - j0);
+    sv.load(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j0 * p.v.sn, p.v.sn, p.M - j0);
+    if constexpr (ROWS_AHEAD) load_rows(red_, nq, ndo);
     if (i < p.N) {
       const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
       ninvl = p.inv_l[ridx];
@@ -631,10 +644,18 @@ __global__ void __launch_bounds__(256, (D * Traits<T>::ES <= 256 ? 2 : 1)) bwd_d
   for (int red = 0; red < n_red; ++red) {
     // this lane's row: Q^ and dO fragments (B operands), log2-normaliser and delta
     u32x4 qf[G::KS], dof[G::KS];
+    if constexpr (ROWS_AHEAD) {
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) {
-      qf[kk] = p.q_scaled ? nq[kk] : scale_frag<T>(nq[kk], p.c1);
-      dof[kk] = ndo[kk];
+      for (int kk = 0; kk < G::KS; ++kk) {
+        qf[kk] = p.q_scaled ? nq[kk] : scale_frag<T>(nq[kk], p.c1);
+        dof[kk] = ndo[kk];
+      }
+    } else {
+      load_rows(red, qf, dof);
+      if (!p.q_scaled) {
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) qf[kk] = scale_frag<T>(qf[kk], p.c1);
+      }
     }
     const float lc = i < p.N ? (p.invl_log2 ? ninvl : __builtin_amdgcn_logf(ninvl)) - p.c2 : 0.f, delta = i < p.N ? ndelta : 0.f;
     const uint64_t word = __ballot((j0 + lane) < p.M && nmask != 0);     // valid keys of this tile for this batch element
@@ -751,16 +772,18 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     FCSA_STAMP(ts, 2 + 3 * ib);
 
     f32x16 pr;
+    // (this lane's column of the transposed bias block; recomputed per block so that it does not live across the tile loops)
+    const char* bcol = BIAS ? bscr + 4 * fa.hi * BiasBlock<T>::PITCH + (opaque(lane) & 31) * TR::ES : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float x = s[r];                 // = c1 * qh.kh + lc already
       if constexpr (BIAS) {
         if (bvec) {
-          x += BiasBlock<T>::value(bscr, crow(r, 0) + 4 * fa.hi, lane) * p.bias_c;
+          x += (float)*reinterpret_cast<const typename TR::elem*>(bcol + crow(r, 0) * BiasBlock<T>::PITCH) * p.bias_c;
         } else {                // element loads; clamped row: always a valid address; rows >= N have P = 0 through lc = -inf
           const int i = min(i0 + 32 * ib + crow(r, 0) + 4 * fa.hi, p.N - 1);
           const typename TR::elem bv = *reinterpret_cast<const typename TR::elem*>(
-              bias_col + (int64_t)i * p.M * (int64_t)sizeof(typename TR::elem));
+              bias_col + ((int64_t)i * p.M + min(j, p.M - 1)) * (int64_t)sizeof(typename TR::elem));
           x += (float)bv * p.bias_c;
         }
       }
@@ -1034,14 +1057,14 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
   geometry(pass, n0, t0);
   const int nw = n0 + wave * 32;                        // first key of this wave
   const int j = nw + (lane & 31);                       // this lane's key
-  const char* bias_col = nullptr;                 // column min(j, M-1): always a valid address
+  const char* bias_col = nullptr;                 // &bias[slice][0][0] (wave-uniform: the element-load fallback adds row and column itself)
   const char* bias_blk = nullptr;                 // &bias[slice][0][first key of this wave]
   BiasBlock<T> bb;
   char* bscr = smem + LDS::TOTAL + wave * BiasBlock<T>::BYTES;      // private scratch of the bias transposition (BIAS launches only)
   bool bvec = false;                              // whole key tile inside M, rows 16-byte aligned: block loads (BiasBlock)
   if constexpr (BIAS) {
     const char* slice = p.bias + (int64_t)(p.bias_batch ? b : h) * p.N * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
-    bias_col = slice + (int64_t)min(j, p.M - 1) * (int64_t)sizeof(typename TR::elem);
+    bias_col = slice;
     bias_blk = slice + (int64_t)nw * (int64_t)sizeof(typename TR::elem);
     bvec = n0 + BNK <= p.M && ((int64_t)p.M * TR::ES) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     if (bvec && t0 < QT) bb.request(bias_blk, min(t0 * BMQ + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);

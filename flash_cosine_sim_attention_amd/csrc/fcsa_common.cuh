@@ -189,7 +189,8 @@ template <typename T> struct BiasBlock {
 #pragma unroll
     for (int v = 0; v < NV; ++v) raw[v] = *reinterpret_cast<const u32x4*>(src + 16 * v);
   }
-  FCSA_DEV void stage(char* scr, int lane) const {
+  FCSA_DEV void stage(char* scr, int lane_) const {
+    const int lane = opaque(lane_);      // (address recomputed per block: hoisted, it is one more register that lives across the tile loops)
     char* dst = scr + (lane & 31) * PITCH + (lane >> 5) * (KB / 2);
 #pragma unroll
     for (int v = 0; v < NV; ++v) *reinterpret_cast<u32x4*>(dst + 16 * v) = raw[v];

@@ -25,12 +25,16 @@ def summarize(path):
             continue
         if cur is not None:
             body.append(line)
-        m = re.match(r"\s*\.(vgpr_count|sgpr_spill_count|vgpr_spill_count|private_segment_fixed_size|agpr_count):\s*(\d+)", line)
-        if m: meta.setdefault("pending", {})[m.group(1)] = int(m.group(2))
-        m = re.match(r"\s*\.name:\s*(\S+)", line)
-        if m and "pending" in meta:
-            meta[m.group(1)] = meta.pop("pending")
-        m = re.match(r"\s*- \.agpr_count", line)
+    # amdhsa.kernels metadata: one entry per kernel, starting at "  - .agpr_count:"; the kernel's own keys are indented 4 spaces
+    text = open(path).read()
+    for ent in re.split(r"\n  - (?=\.agpr_count:)", text)[1:]:
+        nm = re.search(r"^    \.name:\s*(\S+)", ent, flags=re.M)
+        if not nm: continue
+        d = {}
+        for key in ("vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size", "agpr_count"):
+            mm = re.search(r"^(?:    |)\." + key + r":\s*(\d+)", ent, flags=re.M)
+            if mm: d[key] = int(mm.group(1))
+        meta[nm.group(1)] = d
     for k, v in meta.items():
         if k in res: res[k].update(v)
     return res
