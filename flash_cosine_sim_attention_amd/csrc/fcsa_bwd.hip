@@ -33,7 +33,11 @@
 
 namespace fcsa {
 // Tuning constants (each settled by a same-box A/B on MI355X; the rejected alternatives are listed in DESIGN.md §8):
-constexpr int kDq2WBytes = 128;      // row bytes D*ES up to which the dQ kernel asks for 2 waves / SIMD (<= 256 registers)
+constexpr int kDq2WBytes = 128;      // row bytes D*ES up to which the dQ kernel runs its 8-wave form (two waves / SIMD, one workgroup per CU)
+// Two waves per SIMD (<= 256 registers) for the dQ kernel: rows up to 128 bytes, and -- round 3 -- 16-bit rows up to 256 bytes
+// (D = 96, 128) in the 4-wave form, i.e. two 128-row workgroups per CU whose waves hide each other's LDS latency.  Those widths ran
+// one wave per SIMD before (435 registers at D = 128), at ~40 % of what the same kernel reaches at D = 64.
+template <typename T, int D> constexpr bool dq_two_waves() { return D * Traits<T>::ES <= (Traits<T>::ES == 2 ? 256 : 128); }
 constexpr int kDkv2WBytes = 128;     // same for the dKV kernel
 constexpr int kDqSub8 = 4;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
 constexpr int kDkvBmq8 = 128;        // staged query rows of the 8-wave dKV kernel
@@ -190,7 +194,7 @@ template <typename T, int D> constexpr bool dq_dma(int sub) {
 }
 template <typename T, int D, int NW, int SUB> struct DqLds
     : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB, dq_dma<T, D>(SUB),
-             ((NW == 8 || D * Traits<T>::ES > kDq2WBytes) ? 160 : 80) * 1024> {};
+             ((NW == 8 || !dq_two_waves<T, D>()) ? 160 : 80) * 1024> {};
 
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
 template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
@@ -202,7 +206,7 @@ template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
 template <typename T, int D, int NW, bool BIAS, int SUB>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDq2WBytes ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+__global__ void __launch_bounds__(NW * 64, (dq_two_waves<T, D>() ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64, BNS = BN * SUB;
@@ -458,7 +462,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDq2WBytes ? 2 
         }
       }
       FCSA_STAMP(ts, 1);
-      if constexpr (TR::ES == 2 && !BIAS && D * TR::ES > kDq2WBytes) {      // pipelined tile: one wave per SIMD only
+      if constexpr (TR::ES == 2 && !BIAS && !dq_two_waves<T, D>()) {      // pipelined tile: one wave per SIMD only (no 16-bit width left: kept for A/B)
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer

@@ -49,6 +49,16 @@ __device__ unsigned long long g_trace_wg_fwd[2048];      // per workgroup: [2 * 
 __device__ unsigned long long g_trace_pass_fwd[2560];     // per workgroup (first 256): [pass][5] pass marks of wave 0
 #endif
 
+// "Lean" form of the 32-rows-per-wave kernel for 16-bit rows of 129 .. 256 bytes (D = 96, 128) without bias: nothing is prefetched
+// across blocks -- K row fragments and V transposed fragments are requested per 32-key block, next to their MFMAs -- so the wave
+// fits 256 registers and TWO waves share a SIMD (eight waves per CU), the partner hiding the LDS latency the prefetches hid.
+// The round-2 form prefetched a whole tile's K fragments and ran one wave per SIMD at these widths (397 registers at D = 128);
+// measured on MI355X (C3 at D = 128, profiles/r03_*): see DESIGN.md section 6.
+template <typename T, int D, bool BIAS> constexpr bool fwd_lean() {
+  return Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES > 128 && D * Traits<T>::ES <= 256;
+}
+template <typename T, int D, bool BIAS> constexpr int fwd_waves_per_simd() { return (D * Traits<T>::ES <= 128 || fwd_lean<T, D, BIAS>()) ? 2 : 1; }
+
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
 template <typename T, bool MASKED, bool BIAS>
 FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lacc, const FwdParams& p, uint32_t w,
@@ -90,10 +100,11 @@ template <typename T, int D, bool MASKED, bool BIAS, typename Mid>
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, f32x16& lacc, const FwdParams& p, float c2row, uint64_t word, uint32_t ncm, int i, int j0, int diff,
-                       const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k) {
+                       const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k, const char* kt) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  constexpr bool PREFETCH_K = D * TR::ES < 512;     // see fwd_kernel
+  constexpr bool LEAN = fwd_lean<T, D, BIAS>();
+  constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;     // see fwd_kernel
   // validity bits of this lane's 16 keys per block.  Branch-free and BEFORE the MFMA chains on purpose: a runtime
   // branch between the last MFMA and the first read of its result gets too few wait states on the
   // taken path (hipcc 7.2 pads only the fall-through; seen with the 16-pass v_mfma_f32_32x32x2_f32).
@@ -104,7 +115,49 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       w[jb] = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
   }
 
-  if constexpr (TR::ES == 2 && !BIAS) {
+  if constexpr (LEAN) {
+    // per 32-key block: K fragments (4 k-steps at a time) -> S chain; V fragments of the block requested behind the chain, landing
+    // during exp / pack; row sum on the matrix pipe; PV.  Everything is read from the LDS tile here (`kf` is unused).
+    const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = -c2row;
+      constexpr int PF = 4;
+#pragma unroll
+      for (int k0 = 0; k0 < G::KS; k0 += PF) {
+        u32x4 kfr[PF];
+#pragma unroll
+        for (int kk = 0; kk < PF; ++kk)
+          if (k0 + kk < G::KS) kfr[kk] = fa.row_frag(kt, 32 * jb, k0 + kk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < PF; ++kk)
+          if (k0 + kk < G::KS) s = TR::mfma32(kfr[kk], qf[k0 + kk], s);
+      }
+      u32x4 vf[G::DB][2];
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db) { vf[db][0] = fa.tr_frag(vt, 32 * jb, db); vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = fast_exp2(s[r]);
+        if constexpr (MASKED) e = ((w[jb] >> crow(r, 0)) & 1u) ? e : 0.f;
+        s[r] = e;
+      }
+      SecondB<T> pb;
+      pb.prep(s);
+      lacc = TR::mfma32(ones, pb.v[0], lacc);
+      lacc = TR::mfma32(ones, pb.v[1], lacc);
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db) {
+        o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
+        o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
+      }
+    }
+    mid();
+  } else if constexpr (TR::ES == 2 && !BIAS) {
     constexpr int MFMA = 0x8, VALU = 0x2 | 0x400, DSR = 0x100;
     f32x16 s0, s1;
 #pragma unroll
@@ -261,6 +314,9 @@ FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const Frag
       }
       const int sh = p.lgm >= 1 ? p.lgm - 1 : 0;         // k-steps per group = 1 << sh
       const int64_t row = ((int64_t)b * p.H + h) * p.N + i;
+      // (the lane half comes from an opaque value: derived from fa.hi, the 2 * KS lane-constant address pairs of the conditional
+      //  stores below are hoisted to kernel entry, live across the whole kernel and get spilled in the wider instantiations)
+      const int hi_ = opaque(fa.hi);
 #pragma unroll
       for (int kk = 0; kk < G::KS; ++kk) {
         float tot = 0.f;
@@ -269,7 +325,7 @@ FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const Frag
         const float r = 1.f / fmaxf(sqrtf(tot), p.norm_eps);
         qf[kk] = scale_frag<T>(qf[kk], r * p.c1);
         if (i < p.N) {
-          const int c = 2 * kk + fa.hi;
+          const int c = 2 * kk + hi_;
           if (p.qn_out != nullptr) *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];      // (inference: nothing is saved)
           if (p.rq_out != nullptr && (c & ((1 << p.lgm) - 1)) == 0) p.rq_out[row * p.G + (c >> p.lgm)] = r;
         }
@@ -299,7 +355,7 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 // DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
 // the main loop then starts the S accumulators from -max instead of the static shift; inv_l is saved for shift 0.
 template <typename T, int D, int NW, bool BIAS, bool DYN>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) fwd_kernel(const FwdParams p) {
+__global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) fwd_kernel(const FwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
@@ -509,7 +565,8 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   __syncthreads();
   FCSA_PASS_MARK(2);
   // K fragments of a tile are 8 * KS registers; 512-byte rows (f32, D = 128) cannot hold them across the PV products
-  constexpr bool PREFETCH_K = D * TR::ES < 512;
+  constexpr bool LEAN = fwd_lean<T, D, BIAS>();      // K fragments are read per block inside the tile
+  constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;
   if (PREFETCH_K && nt > 0) request_k(smem);
 
   // tiles [0, t_split) need no masking for THIS wave, tiles [t_split, nt) do (wave-uniform split; both
@@ -579,12 +636,13 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
       };
       bool skip = false;
       if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
-      if (!PREFETCH_K && !skip) request_k(vcur - SUB * TILE_B);
+      if (!LEAN && !PREFETCH_K && !skip) request_k(vcur - SUB * TILE_B);
       if (skip) {
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
       } else {
-        fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt);
+        fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
+                                     vcur - SUB * TILE_B);
       }
       FCSA_STAMP(ts, 10);
       if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only
@@ -616,7 +674,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= 128 ? 2 : 1)) f
   {
     typedef RowEpilogue<T, D> EP;
     if (p.N - mw > 0)
-      EP::store(smem + wave * EP::BYTES_NOX, o, inv, lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
+      EP::store(smem + wave * EP::BYTES_NOX, o, inv, opaque(lane), p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
                 p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     if (pass + 1 < npass) __syncthreads();
   }
@@ -1046,7 +1104,7 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   if (p.dyn) return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);      // dynamic-shift path: one (4-wave) form
   if (p.splits > 1) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);   // split-key path: 128-row tiles x key ranges
-  if constexpr (D * Traits<T>::ES <= 128) {      // the two-waves-per-SIMD instantiations
+  if constexpr (fwd_waves_per_simd<T, D, BIAS>() == 2) {      // the two-waves-per-SIMD instantiations
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   }
   return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);

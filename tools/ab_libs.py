@@ -9,17 +9,10 @@ from flash_cosine_sim_attention_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--shape", default="4,8,4096,64,1")
+ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal; several shapes separated by ':'")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("tags", nargs="+")
 a = ap.parse_args()
-B, H, N, D, causal = (int(x) for x in a.shape.split(","))
-dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
-q, k, v = (torch.randn(B, H, N, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(3))
-do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
-def step():
-    q.grad = k.grad = v.grad = None
-    F.flash_cosine_sim_attention(q, k, v, causal=bool(causal)).backward(do)
 import ctypes
 from flash_cosine_sim_attention_amd import _torch_ops
 _torch_ops.load()
@@ -36,32 +29,43 @@ def open_lib(path):
 for t in a.tags:
     paths[t] = os.path.join(pkg, "libfcsa_hip.so" if t == "main" else f"libfcsa_hip_{t}.so")
     libs[t] = open_lib(paths[t])
-res = {t: {} for t in a.tags}
-for r in range(a.rounds + 1):
+def run_shape(shape):
+    B, H, N, D, causal = (int(x) for x in shape.split(","))
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    q, k, v = (torch.randn(B, H, N, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(3))
+    do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
+    def step():
+        q.grad = k.grad = v.grad = None
+        F.flash_cosine_sim_attention(q, k, v, causal=bool(causal)).backward(do)
+    res = {t: {} for t in a.tags}
+    for r in range(a.rounds + 1):
+        for t in a.tags:
+            _lib._lib = libs[t]
+            assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t      # route torch.ops.fcsa.* to this build
+            for _ in range(3): step()
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            for _ in range(a.steps): step()
+            torch.cuda.synchronize()
+            st = _lib.profile_collect()
+            _lib.profile_enable(False)
+            if r == 0: continue          # first round = warm-up
+            for s in st: res[t].setdefault(s["name"], []).append(s["total_ms"] / s["calls"] * 1e3)
+    # same inputs through every build: max |difference| of (o, dq, dk, dv) against the first tag (identical math => expect 0)
+    outs = {}
     for t in a.tags:
         _lib._lib = libs[t]
-        assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t      # route torch.ops.fcsa.* to this build
-        for _ in range(3): step()
-        torch.cuda.synchronize()
-        _lib.profile_enable(True)
-        for _ in range(a.steps): step()
-        torch.cuda.synchronize()
-        st = _lib.profile_collect()
-        _lib.profile_enable(False)
-        if r == 0: continue          # first round = warm-up
-        for s in st: res[t].setdefault(s["name"], []).append(s["total_ms"] / s["calls"] * 1e3)
-# same inputs through every build: max |difference| of (o, dq, dk, dv) against the first tag (identical math => expect 0)
-outs = {}
-for t in a.tags:
-    _lib._lib = libs[t]
-    assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
-    q.grad = k.grad = v.grad = None
-    o = F.flash_cosine_sim_attention(q, k, v, causal=bool(causal))
-    o.backward(do)
-    outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
-for t in a.tags[1:]:
-    print(f"{t} vs {a.tags[0]}: max|diff| o/dq/dk/dv = " + " ".join(f"{(x - y).abs().max().item():.3g}" for x, y in zip(outs[t], outs[a.tags[0]])))
-names = ["fwd", "bwd_dq", "bwd_dkv", "l2norm"]
-print(f"shape {a.shape} {a.dtype}; median (min) us over {a.rounds} interleaved rounds")
-for t in a.tags:
-    print(f"{t:12s} " + "  ".join(f"{n} {statistics.median(res[t][n]):7.1f} ({min(res[t][n]):7.1f})" for n in names if n in res[t]))
+        assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
+        q.grad = k.grad = v.grad = None
+        o = F.flash_cosine_sim_attention(q, k, v, causal=bool(causal))
+        o.backward(do)
+        outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
+    for t in a.tags[1:]:
+        print(f"{t} vs {a.tags[0]}: max|diff| o/dq/dk/dv = " + " ".join(f"{(x - y).abs().max().item():.3g}" for x, y in zip(outs[t], outs[a.tags[0]])))
+    names = ["fwd", "bwd_dq", "bwd_dkv", "l2norm"]
+    print(f"shape {shape} {a.dtype}; median (min) us over {a.rounds} interleaved rounds")
+    for t in a.tags:
+        print(f"{t:12s} " + "  ".join(f"{n} {statistics.median(res[t][n]):7.1f} ({min(res[t][n]):7.1f})" for n in names if n in res[t]))
+
+for _shape in a.shape.split(":"):
+    run_shape(_shape)
