@@ -72,7 +72,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     // request every row fragment of this 32-key block first (just-in-time ds_read_b128 in front of their
     // dependent MFMA were the most expensive item of the forward tile, see fwd_tile)
     // (requests are batched PF k-steps at a time so the live fragments stay within the register budget)
-    constexpr int PF = G::KS <= 4 ? G::KS : 2;
+    constexpr int PF = G::KS <= 4 ? G::KS : (G::KS >= 8 && TR::ES == 2 ? 1 : 2);      // (16-bit D = 128 runs two waves per SIMD: 256 registers)
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = -delta; }  // lc = log2(inv_l) - c2 and -delta ride in as initial values

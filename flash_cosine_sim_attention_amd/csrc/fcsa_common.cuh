@@ -422,11 +422,19 @@ template <typename T, int D, int ROWS, int NW> struct DmaStager {
   static_assert(ROWS * G::ROWB % 1024 == 0, "tile must be a whole number of 1 KiB pieces");
   static constexpr int PER = (NPIECE + NW - 1) / NW;                    // pieces per wave
   static constexpr int ROW_BYTES = D * Traits<T>::ES;
-  int voff[PER];         // loop-invariant source byte offset of this lane inside a tile, per piece
+  // Source byte offset of this lane inside a tile, per piece.  Piece i of a wave starts NW * 1024 / ROWB rows below piece i - 1; when
+  // that is a multiple of the swizzle period (16 rows for every TileGeom) the lane fetches the same chunk column in every piece and
+  // the offsets are voff0 + i * vstep with a wave-uniform step: ONE register instead of PER (the wider kernels sit at their
+  // register budget: the dQ kernel at D = 128 with two waves per SIMD spilled its offsets).
+  static constexpr int ROWS_PER_STEP = NW * 1024 / G::ROWB;
+  static constexpr bool UNIFORM = (NW * 1024) % G::ROWB == 0 && ROWS_PER_STEP % 16 == 0;
+  int voff[UNIFORM ? 1 : PER];
+  int vstep;             // UNIFORM: byte distance between consecutive pieces of this wave (wave-uniform)
 
   FCSA_DEV void init(int64_t pitch, int wave, int lane) {
+    vstep = __builtin_amdgcn_readfirstlane((int)(ROWS_PER_STEP * pitch));
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
+    for (int i = 0; i < (UNIFORM ? 1 : PER); ++i) {
       const int lds_off = (wave + i * NW) * 1024 + lane * 16;           // byte offset inside the LDS tile
       const int row = lds_off / G::ROWB, cp = (lds_off % G::ROWB) >> 4;
       const int c = cp ^ G::swz(row);
@@ -434,6 +442,7 @@ template <typename T, int D, int ROWS, int NW> struct DmaStager {
       voff[i] = (int)(row * pitch + (c < G::CPR ? c : 0) * 16);
     }
   }
+  FCSA_DEV int piece_offset(int i) const { return UNIFORM ? voff[0] + i * vstep : voff[UNIFORM ? 0 : i]; }
   // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write that may alias any later
   // ds_read of the same __shared__ array and drains it (s_waitcnt vmcnt(0)) in front of the next tile's first fragment read,
   // i.e. right after issuing it.  Hidden from the compiler, the transfer overlaps the whole tile; the caller waits for it with
@@ -472,7 +481,7 @@ template <typename T, int D, int ROWS, int NW> struct DmaStager {
       const uint32_t off = __builtin_amdgcn_readfirstlane(st.off), m0v = __builtin_amdgcn_readfirstlane(lds_tile + (uint32_t)(wave + i * NW) * 1024u);
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "s"(m0v), "v"(voff[i] + off), "s"(rs) : "memory");
+                   : "=&s"(keep) : "s"(m0v), "v"(piece_offset(i) + off), "s"(rs) : "memory");
     }
   }
   FCSA_DEV void issue(const Stream& st, uint32_t lds_tile, int wave) const {

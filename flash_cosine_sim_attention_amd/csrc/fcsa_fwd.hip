@@ -300,7 +300,7 @@ FCSA_DEV void request_q_rows(const FwdParams& p, int b, int h, int i, int hi, u3
 }
 // raw row chunks (request_q_rows) -> B operands of the S chains: fused (grouped) l2norm with the c1 * q^ / inverse-norm outputs
 // the backward reads, or the plain c1 scaling
-template <typename T, int D>
+template <typename T, int D, bool OPQ = (D * Traits<T>::ES > 128)>
 FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const FragAddr<T, D>& fa,
                              u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS]) {
   typedef TileGeom<D, Traits<T>::ES> G;
@@ -316,7 +316,9 @@ FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const Frag
       const int64_t row = ((int64_t)b * p.H + h) * p.N + i;
       // (the lane half comes from an opaque value: derived from fa.hi, the 2 * KS lane-constant address pairs of the conditional
       //  stores below are hoisted to kernel entry, live across the whole kernel and get spilled in the wider instantiations)
-      const int hi_ = opaque(fa.hi);
+      //  (OPQ: rows > 128 bytes and the bias + dynamic-shift kernel.  The others keep the hoisted form: with it the C3 kernel measured
+      //   1.3 % faster, registers are not its limit)
+      const int hi_ = OPQ ? opaque(fa.hi) : fa.hi;
 #pragma unroll
       for (int kk = 0; kk < G::KS; ++kk) {
         float tot = 0.f;
@@ -449,7 +451,7 @@ __global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) f
 
   u32x4 qf[G::KS];
   request_q_rows<T, D>(p, b, h, i, fa.hi, qf);
-  finish_q_frags<T, D>(p, b, h, i, fa, qf);
+  finish_q_frags<T, D, (D * TR::ES > 128) || (BIAS && DYN)>(p, b, h, i, fa, qf);
   FCSA_PASS_MARK(1);
 
   f32x16 o[G::DB];
@@ -674,7 +676,7 @@ __global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) f
   {
     typedef RowEpilogue<T, D> EP;
     if (p.N - mw > 0)
-      EP::store(smem + wave * EP::BYTES_NOX, o, inv, opaque(lane), p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
+      EP::store(smem + wave * EP::BYTES_NOX, o, inv, (D * TR::ES > 128 || (BIAS && DYN)) ? opaque(lane) : lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
                 p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     if (pass + 1 < npass) __syncthreads();
   }
