@@ -34,10 +34,11 @@
 namespace fcsa {
 // Tuning constants (each settled by a same-box A/B on MI355X; the rejected alternatives are listed in DESIGN.md §8):
 constexpr int kDq2WBytes = 128;      // row bytes D*ES up to which the dQ kernel runs its 8-wave form (two waves / SIMD, one workgroup per CU)
-// Two waves per SIMD (<= 256 registers) for the dQ kernel: rows up to 128 bytes, and -- round 3 -- 16-bit rows up to 256 bytes
-// (D = 96, 128) in the 4-wave form, i.e. two 128-row workgroups per CU whose waves hide each other's LDS latency.  Those widths ran
-// one wave per SIMD before (435 registers at D = 128), at ~40 % of what the same kernel reaches at D = 64.
-template <typename T, int D> constexpr bool dq_two_waves() { return D * Traits<T>::ES <= (Traits<T>::ES == 2 ? 256 : 128); }
+// Two waves per SIMD (<= 256 registers) for the dQ kernel (template parameter TWO): always for rows up to 128 bytes, and -- round 3 --
+// for 16-bit rows up to 256 bytes (D = 96, 128) in the 4-wave form WHEN the grid puts two 128-row workgroups on every CU, whose waves
+// then hide each other's LDS latency (launch_dq_b).  Those widths ran one wave per SIMD before (435 registers at D = 128), at ~40 %
+// of what the same kernel reaches at D = 64; smaller grids still do (a lone wave is better off with the pipelined tile).
+template <typename T, int D> constexpr bool dq_can_two_waves() { return D * Traits<T>::ES <= (Traits<T>::ES == 2 ? 256 : 128); }
 constexpr int kDkv2WBytes = 128;     // same for the dKV kernel
 constexpr int kDqSub8 = 4;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
 constexpr int kDkvBmq8 = 128;        // staged query rows of the 8-wave dKV kernel
@@ -56,7 +57,7 @@ __device__ unsigned long long g_trace_pass_dkv[2560];
 // =============================================================================================
 // dQ kernel
 // =============================================================================================
-template <typename T, int D, bool MASKED, bool BIAS>
+template <typename T, int D, bool MASKED, bool BIAS, bool TWO>
 FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
                       f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
@@ -72,7 +73,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     // request every row fragment of this 32-key block first (just-in-time ds_read_b128 in front of their
     // dependent MFMA were the most expensive item of the forward tile, see fwd_tile)
     // (requests are batched PF k-steps at a time so the live fragments stay within the register budget)
-    constexpr int PF = G::KS <= 4 ? G::KS : (G::KS >= 8 && TR::ES == 2 ? 1 : 2);      // (16-bit D = 128 runs two waves per SIMD: 256 registers)
+    constexpr int PF = G::KS <= 4 ? G::KS : (G::KS >= 8 && TWO ? 1 : 2);      // (16-bit D = 128 at two waves per SIMD: 256 registers)
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = -delta; }  // lc = log2(inv_l) - c2 and -delta ride in as initial values
@@ -192,9 +193,9 @@ FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, co
 template <typename T, int D> constexpr bool dq_dma(int sub) {
   return (Traits<T>::ES == 2 || D * Traits<T>::ES >= 512) && (64 * sub * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
 }
-template <typename T, int D, int NW, int SUB> struct DqLds
+template <typename T, int D, int NW, int SUB, bool TWO> struct DqLds
     : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB, dq_dma<T, D>(SUB),
-             ((NW == 8 || !dq_two_waves<T, D>()) ? 160 : 80) * 1024> {};
+             ((NW == 8 || !TWO) ? 160 : 80) * 1024> {};
 
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
 template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
@@ -205,8 +206,8 @@ template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
 // SUB = 64-key tiles per LDS stage: 1, or 2 / 4 in the 8-wave form (one workgroup per CU has the LDS for 128- / 256-key stages).
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
-template <typename T, int D, int NW, bool BIAS, int SUB>
-__global__ void __launch_bounds__(NW * 64, (dq_two_waves<T, D>() ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO>
+__global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64, BNS = BN * SUB;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(NW * 64, (dq_two_waves<T, D>() ? 2 : 1)) bwd_d
   // be finished before the next one starts loading: the first K / V stage and this lane's Q^ / dO / O row chunks of the NEXT
   // iteration are requested before the epilogue of the current one and land while it runs (the pass marks of the WG trace showed
   // 11 % of this kernel in prologues and 7 % in epilogues: exposed round trips, every workgroup of the chip in step).
-  typedef DqLds<T, D, NW, SUB> LDS;
+  typedef DqLds<T, D, NW, SUB, TWO> LDS;
   constexpr bool SEP = LDS::SEP;
   Stager<T, D, BNS, NT> sk, sv;
   typedef DmaStager<T, D, DMA ? BNS : 1024, NW> DS;
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(NW * 64, (dq_two_waves<T, D>() ? 2 : 1)) bwd_d
         }
       }
       FCSA_STAMP(ts, 1);
-      if constexpr (TR::ES == 2 && !BIAS && !dq_two_waves<T, D>()) {      // pipelined tile: one wave per SIMD only (no 16-bit width left: kept for A/B)
+      if constexpr (TR::ES == 2 && !BIAS && !TWO) {      // pipelined tile: one wave per SIMD only
         bool skip = false;
         if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
@@ -470,9 +471,9 @@ __global__ void __launch_bounds__(NW * 64, (dq_two_waves<T, D>() ? 2 : 1)) bwd_d
                                               next_here ? t + 1 : -1, t, fa, qf, dof, dq, lc, delta, word, ncm, i, j0, diff, pipe);
       } else if constexpr (MASKED) {
         const bool skip = p.causal && (j0 > mw + 31 + diff);
-        if (!skip) dq_tile<T, D, true, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
+        if (!skip) dq_tile<T, D, true, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
       } else {
-        dq_tile<T, D, false, BIAS>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
+        dq_tile<T, D, false, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
       }
       FCSA_STAMP(ts, 2);
       if (last_of_stage) {                                 // workgroup-uniform
@@ -1281,7 +1282,7 @@ static int tile_waves(int64_t batch_heads, int len, bool causal) {
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
 
-template <typename T, int D, bool BIAS, int NW>
+template <typename T, int D, bool BIAS, int NW, bool TWO>
 static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
@@ -1290,8 +1291,8 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   // one-wave-per-SIMD configurations (16-bit D >= 96: one workgroup per CU, the LDS is there)
   // 8-wave form: 256-key stages where they arrive by LDS-DMA (no staging registers), 128-key stages through registers (f32)
   constexpr int SUB = NW == 8 ? (Traits<T>::ES == 2 ? kDqSub8 : 2) : 1;
-  const size_t lds = DqLds<T, D, NW, SUB>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
-  auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB>;
+  const size_t lds = DqLds<T, D, NW, SUB, TWO>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
+  auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1)), dim3(NW * 64), lds, s, p);
@@ -1300,11 +1301,16 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
-  if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4>(p, s);       // split-key path: 128-row tiles x key ranges
-  if constexpr (D * Traits<T>::ES <= kDq2WBytes) {
-    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8>(p, s);
+  constexpr bool NARROW = D * Traits<T>::ES <= kDq2WBytes;      // rows <= 128 bytes: two waves per SIMD whatever the grid
+  if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges
+  if constexpr (NARROW) {
+    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
+  } else if constexpr (dq_can_two_waves<T, D>()) {
+    // two waves per SIMD need two 128-row workgroups on every CU; smaller grids keep the one-wave (pipelined) form
+    const int MT4 = (p.N + 127) / 128;
+    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= 448) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
   }
-  return launch_dq_nw<T, D, BIAS, 4>(p, s);
+  return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);
 }
 
 template <typename T, int D, bool BIAS, int NW>

@@ -54,10 +54,11 @@ __device__ unsigned long long g_trace_pass_fwd[2560];     // per workgroup (firs
 // fits 256 registers and TWO waves share a SIMD (eight waves per CU), the partner hiding the LDS latency the prefetches hid.
 // The round-2 form prefetched a whole tile's K fragments and ran one wave per SIMD at these widths (397 registers at D = 128);
 // measured on MI355X (C3 at D = 128, profiles/r03_*): see DESIGN.md section 6.
+// It only pays when two waves per SIMD are actually resident -- an 8-wave workgroup per CU, or two 4-wave workgroups -- so it is a
+// kernel template parameter chosen at launch (launch_fwd_b); small grids keep the prefetching one-wave form.
 template <typename T, int D, bool BIAS> constexpr bool fwd_lean() {
   return Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES > 128 && D * Traits<T>::ES <= 256;
 }
-template <typename T, int D, bool BIAS> constexpr int fwd_waves_per_simd() { return (D * Traits<T>::ES <= 128 || fwd_lean<T, D, BIAS>()) ? 2 : 1; }
 
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
 template <typename T, bool MASKED, bool BIAS>
@@ -96,14 +97,13 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
 // next tile's fragments land during the PV products instead of being waited for at the top of the next tile
 // (phase timing of the previous structure: 690 of 2490 cycles per tile were spent there, right after the barrier,
 // with all four waves bursting their K reads at once).
-template <typename T, int D, bool MASKED, bool BIAS, typename Mid>
+template <typename T, int D, bool MASKED, bool BIAS, bool LEAN, typename Mid>
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, f32x16& lacc, const FwdParams& p, float c2row, uint64_t word, uint32_t ncm, int i, int j0, int diff,
                        const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k, const char* kt) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  constexpr bool LEAN = fwd_lean<T, D, BIAS>();
   constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;     // see fwd_kernel
   // validity bits of this lane's 16 keys per block.  Branch-free and BEFORE the MFMA chains on purpose: a runtime
   // branch between the last MFMA and the first read of its result gets too few wait states on the
@@ -300,7 +300,7 @@ FCSA_DEV void request_q_rows(const FwdParams& p, int b, int h, int i, int hi, u3
 }
 // raw row chunks (request_q_rows) -> B operands of the S chains: fused (grouped) l2norm with the c1 * q^ / inverse-norm outputs
 // the backward reads, or the plain c1 scaling
-template <typename T, int D, bool OPQ = (D * Traits<T>::ES > 128)>
+template <typename T, int D, bool OPQ = false>
 FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const FragAddr<T, D>& fa,
                              u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS]) {
   typedef TileGeom<D, Traits<T>::ES> G;
@@ -316,8 +316,8 @@ FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const Frag
       const int64_t row = ((int64_t)b * p.H + h) * p.N + i;
       // (the lane half comes from an opaque value: derived from fa.hi, the 2 * KS lane-constant address pairs of the conditional
       //  stores below are hoisted to kernel entry, live across the whole kernel and get spilled in the wider instantiations)
-      //  (OPQ: rows > 128 bytes and the bias + dynamic-shift kernel.  The others keep the hoisted form: with it the C3 kernel measured
-      //   1.3 % faster, registers are not its limit)
+      //  (OPQ: the lean two-waves-per-SIMD forms and the bias + dynamic-shift kernel.  The others keep the hoisted form: with it the C3
+      //   kernel measured 1.3 % faster, registers are not its limit)
       const int hi_ = OPQ ? opaque(fa.hi) : fa.hi;
 #pragma unroll
       for (int kk = 0; kk < G::KS; ++kk) {
@@ -356,8 +356,8 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 
 // DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
 // the main loop then starts the S accumulators from -max instead of the static shift; inv_l is saved for shift 0.
-template <typename T, int D, int NW, bool BIAS, bool DYN>
-__global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) fwd_kernel(const FwdParams p) {
+template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN>
+__global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) f
 
   u32x4 qf[G::KS];
   request_q_rows<T, D>(p, b, h, i, fa.hi, qf);
-  finish_q_frags<T, D, (D * TR::ES > 128) || (BIAS && DYN)>(p, b, h, i, fa, qf);
+  finish_q_frags<T, D, LEAN || (BIAS && DYN)>(p, b, h, i, fa, qf);
   FCSA_PASS_MARK(1);
 
   f32x16 o[G::DB];
@@ -567,8 +567,7 @@ __global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) f
   __syncthreads();
   FCSA_PASS_MARK(2);
   // K fragments of a tile are 8 * KS registers; 512-byte rows (f32, D = 128) cannot hold them across the PV products
-  constexpr bool LEAN = fwd_lean<T, D, BIAS>();      // K fragments are read per block inside the tile
-  constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;
+  constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;      // (LEAN: K fragments are read per block inside the tile)
   if (PREFETCH_K && nt > 0) request_k(smem);
 
   // tiles [0, t_split) need no masking for THIS wave, tiles [t_split, nt) do (wave-uniform split; both
@@ -643,7 +642,7 @@ __global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) f
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
       } else {
-        fwd_tile<T, D, MASKED, BIAS>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
+        fwd_tile<T, D, MASKED, BIAS, LEAN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
                                      vcur - SUB * TILE_B);
       }
       FCSA_STAMP(ts, 10);
@@ -676,7 +675,7 @@ __global__ void __launch_bounds__(NW * 64, (fwd_waves_per_simd<T, D, BIAS>())) f
   {
     typedef RowEpilogue<T, D> EP;
     if (p.N - mw > 0)
-      EP::store(smem + wave * EP::BYTES_NOX, o, inv, (D * TR::ES > 128 || (BIAS && DYN)) ? opaque(lane) : lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
+      EP::store(smem + wave * EP::BYTES_NOX, o, inv, (LEAN || (BIAS && DYN)) ? opaque(lane) : lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
                 p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     if (pass + 1 < npass) __syncthreads();
   }
@@ -1083,14 +1082,14 @@ __global__ void __launch_bounds__(256) fwd_combine_kernel(const FwdParams p) {
   if (c == 0 && p.inv_l != nullptr) p.inv_l[row] = inv;
 }
 
-template <typename T, int D, bool BIAS, int NW, bool DYN>
+template <typename T, int D, bool BIAS, int NW, bool DYN, bool LEAN = false>
 static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   size_t lds = 4 * 64 * fwd_stage_tiles<T, D, DYN>() * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K + V tiles of a stage)
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES_NOX) lds = (size_t)NW * RowEpilogue<T, D>::BYTES_NOX;   // epilogue scratch reuses the same bytes
-  auto kern = fwd_kernel<T, D, NW, BIAS, DYN>;
+  auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT), (unsigned)(p.splits > 1 ? p.splits : 1)), dim3(NW * 64), lds, s, p);
@@ -1106,8 +1105,13 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   if (p.dyn) return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);      // dynamic-shift path: one (4-wave) form
   if (p.splits > 1) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);   // split-key path: 128-row tiles x key ranges
-  if constexpr (fwd_waves_per_simd<T, D, BIAS>() == 2) {      // the two-waves-per-SIMD instantiations
+  if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
+  } else if constexpr (fwd_lean<T, D, BIAS>()) {
+    // the lean form needs its partner wave: one 8-wave workgroup per CU, or enough 4-wave workgroups for two per CU
+    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
+    const int MT4 = (p.N + 127) / 128;
+    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= 448) return launch_fwd_nw<T, D, BIAS, 4, false, true>(p, s);
   }
   return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
 }
