@@ -1011,15 +1011,17 @@ __global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
 
 // Wide or narrow forward kernel (measured on MI355X, bf16, B4 H8: tools/fwd_ab.py).  The wide kernel needs enough
 // 256-row workgroups to cover the 256 CUs.  It wins where the MFMA share of a tile is large or the sequence is long
-// (D = 96: +25..34%; D = 32 / 64 non-causal: +3..22%; causal N = 8192: +5%); with causal masking and short sequences
-// its 256-row diagonal granularity costs more than the halved LDS traffic saves (N = 4096: -6%, N = 1024: -20%).
+// (D = 32 / 64 non-causal: +3..22%; causal N = 8192: +5%; D = 96 against the ONE-wave narrow kernel of round 2: +25..34%);
+// with causal masking and short sequences its 256-row diagonal granularity costs more than the halved LDS traffic saves
+// (N = 4096: -6%, N = 1024: -20%).
 template <int D>
 static bool use_wide_fwd(const FwdParams& p) {
   const int MT = (p.N + 255) / 256;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
   if (wgs < 224) return false;
+  if (D == 96) return false;      // round 3: the lean two-waves-per-SIMD 32-row kernel beats it at D = 96 (-1 ... -6 %, profiles/r03_ab_d96_lean_vs_wide.txt)
   if (!p.causal) return D >= 32;
-  return D == 96 ? p.N >= 2048 : p.N >= 8192;
+  return p.N >= 8192;
 }
 
 template <typename T, int D>
