@@ -198,10 +198,14 @@ template <typename T, int D, int NW, int SUB, bool TWO> struct DqLds
              ((NW == 8 || !TWO) ? 160 : 80) * 1024> {};
 
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
-template <typename T, int D, int NW, int BMQ, bool BIAS> struct DkvLds
-    : EpiLds<T, D, NW, 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4),
-             Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
-             ((NW == 8 || D * Traits<T>::ES > kDkv2WBytes) ? 160 : 80) * 1024> {};
+// LEAN (16-bit rows of 129 .. 256 bytes, two waves per SIMD): the V rows of the workgroup's own keys live in the LDS behind the staging
+// buffers instead of in registers (VOWN bytes); the epilogue scratch then shares those bytes (never "SEP").
+template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false> struct DkvLds
+    : EpiLds<T, D, NW, 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4) + (LEAN ? 32 * NW * TileGeom<D, Traits<T>::ES>::ROWB : 0),
+             !LEAN && Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+             ((NW == 8 || (D * Traits<T>::ES > kDkv2WBytes && !LEAN)) ? 160 : 80) * 1024> {
+  static constexpr int VOWN = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);      // byte offset of the own-V tile (LEAN)
+};
 
 // SUB = 64-key tiles per LDS stage: 1, or 2 / 4 in the 8-wave form (one workgroup per CU has the LDS for 128- / 256-key stages).
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
@@ -738,16 +742,21 @@ static hipError_t launch_dbias_t(const BwdParams& p, hipStream_t s) {
 // =============================================================================================
 // dK / dV kernel
 // =============================================================================================
-template <typename T, int D, int BMQ, bool MASKED, bool BIAS>
+// LEAN: the B operand of the dP chain (this lane's V row) is read from `vown`, the LDS copy of the workgroup's own V rows, next to
+// each MFMA instead of being held in registers (`vf` is unused): with the dk / dv accumulators (128 registers at D = 128) and the K
+// fragments this is what lets the kernel run two waves per SIMD at 16-bit D = 96 / 128.
+template <typename T, int D, int BMQ, bool MASKED, bool BIAS, bool LEAN = false>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
                        const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col, Trace& ts,
-                       BiasBlock<T>& bb, char* bscr, const char* bias_blk, bool bvec, int next_i0, int lane) {
+                       BiasBlock<T>& bb, char* bscr, const char* bias_blk, bool bvec, int next_i0, int lane, const char* vown = nullptr,
+                       int vrow0 = 0) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
 #pragma unroll
   for (int ib = 0; ib < BMQ / 32; ++ib) {
+    if constexpr (LEAN) FCSA_FENCE();      // blocks stay apart: interleaved by the scheduler, two blocks' fragments do not fit 256 registers
     if constexpr (BIAS) {
       if (bvec) {      // this block's bias values (requested one block ago) -> scratch; request the next block's (see BiasBlock)
         bb.stage(bscr, lane);
@@ -772,8 +781,13 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     //  batching the requests as in dq_tile spills)
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(fa.row_frag(qt, 32 * ib, kk), kf[kk], s);
+    if constexpr (LEAN) {
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), vf[kk], dp);
+      for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), fa.row_frag(vown, vrow0, kk), dp);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) dp = TR::mfma32(fa.row_frag(dot, 32 * ib, kk), vf[kk], dp);
+    }
     FCSA_STAMP(ts, 2 + 3 * ib);
 
     f32x16 pr;
@@ -917,13 +931,14 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
   }
 }
 
-template <typename T, int D, int NW, int BMQ, bool BIAS>
-__global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false>
+__global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes || LEAN) ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
   constexpr int TILE_B = BMQ * G::ROWB;
-  constexpr bool PIPE = Traits<T>::ES == 2 && !BIAS;      // software-pipelined tile (dkv_tile_pipe)
+  static_assert(!LEAN || (Traits<T>::ES == 2 && !BIAS), "lean form: 16-bit types without bias");
+  constexpr bool PIPE = Traits<T>::ES == 2 && !BIAS && !LEAN;      // software-pipelined tile (dkv_tile_pipe)
   constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 4;                // Q tile | dO tile | lc[BMQ] | -delta[BMQ]
   static_assert(BMQ % 32 == 0 && BMQ <= NT, "query tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF_B]
@@ -962,18 +977,20 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
   // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
-  constexpr bool DMA = PIPE && (BMQ * G::ROWB) % 1024 == 0;
-  typedef DkvLds<T, D, NW, BMQ, BIAS> LDS;
+  constexpr bool DMA = (PIPE || LEAN) && (BMQ * G::ROWB) % 1024 == 0;
+  typedef DkvLds<T, D, NW, BMQ, BIAS, LEAN> LDS;
   constexpr bool SEP = LDS::SEP;      // see bwd_dq_kernel: the next pass is requested from inside the epilogue of the current one
   Stager<T, D, BMQ, NT> sq, sdo;
   typedef DmaStager<T, D, DMA ? BMQ : 1024, NW> DS;
   DS dq_, ddo_;
+  DmaStager<T, D, LEAN ? BNK : 1024, NW> dvown_;      // LEAN: the workgroup's own V rows, staged once per pass
   typename DS::Stream stq, stdo;      // Q / dO walked tile by tile from the pass's first tile (DMA form)
   uint32_t q_step = 0, do_step = 0, lds0 = 0;
   bool far = false;
   if constexpr (DMA) {
     dq_.init(p.q.sn, wave, lane);
     ddo_.init(p.d_out.sn, wave, lane);
+    if constexpr (LEAN) dvown_.init(p.v.sn, wave, lane);
     q_step = (uint32_t)(BMQ * p.q.sn);
     do_step = (uint32_t)(BMQ * p.d_out.sn);
     far = BMQ * p.q.sn > (int64_t)DS::REBASE || BMQ * p.d_out.sn > (int64_t)DS::REBASE;
@@ -1034,6 +1051,9 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
         load_rows(t0_ * BMQ);
       }
     }
+    if constexpr (LEAN) {      // the V rows of this workgroup's keys -> LDS (rows past M are zero-filled by the descriptor's range check)
+      dvown_.issue(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)n0_ * p.v.sn, p.v.sn, p.M - n0_, smem + LDS::VOWN, wave);
+    }
     const int ln = opaque(lane), hi_ = ln >> 5;
     const int nw_ = n0_ + wave * 32, j_ = nw_ + (ln & 31);
     const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j_ * p.k.sn;
@@ -1045,7 +1065,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
       rv_[kk] = z;
       if (j_ < p.M) {
         rk_[kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + hi_) * 16);
-        rv_[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + hi_) * 16);
+        if constexpr (!LEAN) rv_[kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + hi_) * 16);
       }
     }
     rmask = (p.mask != nullptr && j_ < p.M) ? p.mask[(int64_t)b * p.M + j_] : (uint8_t)1;
@@ -1101,7 +1121,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
 #pragma unroll
   for (int kk = 0; kk < G::KS; ++kk) {
     kf[kk] = p.q_scaled ? rk_[kk] : scale_frag<T>(rk_[kk], p.c1);     // S = Q (c1 K)^T when the Q tile is plain q^
-    vf[kk] = rv_[kk];
+    if constexpr (!LEAN) vf[kk] = rv_[kk];
   }
   float rinv[RowEpilogue<T, D>::NP];
   if constexpr (SEP) {
@@ -1119,6 +1139,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
   if (t0 < QT) store_tile(smem);
+  if constexpr (LEAN) dma_wait();      // the own-V tile (also on the no-tile path: its bytes are the epilogue's scratch)
   __syncthreads();
   // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
   // Otherwise hipcc's waitcnt model keeps them pending along the no-tile path, the loop-header merge never
@@ -1145,7 +1166,7 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
       FCSA_STAMP(ts, 0);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
-      if constexpr (PIPE && DMA) {
+      if constexpr (DMA) {
         // the next tile arrives by LDS-DMA, all pieces requested at the top of this tile
         if (more) {
           advance(t + 1);
@@ -1157,28 +1178,26 @@ __global__ void __launch_bounds__(NW * 64, (D * Traits<T>::ES <= kDkv2WBytes ? 2
           dq_.issue(stq, lds_nxt, wave);
           ddo_.issue(stdo, lds_nxt + TILE_B, wave);
         }
-        bool skip = false;
-        if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
-        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
       } else {
-      if (more) load_tile(t + 1, nxt);
-      FCSA_STAMP(ts, 1);
+        if (more) load_tile(t + 1, nxt);
+        FCSA_STAMP(ts, 1);
+      }
+      {
+      bool skip = false;
+      if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
       if constexpr (PIPE) {
-        bool skip = false;
-        if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
         if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
-      } else if constexpr (MASKED) {
-        const bool skip = p.causal && (i0 + BMQ - 1 + diff < nw);           // no valid pair for this wave
+      } else if constexpr (LEAN) {
+        if (!skip) dkv_tile<T, D, BMQ, MASKED, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
+                                                            bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32);
+      } else {
         const int next_i0 = more ? i0 + BMQ : -1;
         if (!skip) {
-          dkv_tile<T, D, BMQ, true, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
-                                          bias_blk, bvec, next_i0, lane);
+          dkv_tile<T, D, BMQ, MASKED, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
+                                            bias_blk, bvec, next_i0, lane);
         } else if constexpr (BIAS) {      // the block requested for this tile is not used: request the next tile's first block instead
           if (bvec && more) bb.request(bias_blk, min(next_i0 + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
         }
-      } else {
-        dkv_tile<T, D, BMQ, false, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
-                                         bias_blk, bvec, more ? i0 + BMQ : -1, lane);
       }
       }
       FCSA_STAMP(ts, 8);
@@ -1313,7 +1332,7 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);
 }
 
-template <typename T, int D, bool BIAS, int NW>
+template <typename T, int D, bool BIAS, int NW, bool LEAN = false>
 static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BNK = 32 * NW;
   // staged query tile: 32 rows for wide feature rows (16-bit D >= 96, f32 D >= 64: VGPR budget of the staging registers),
@@ -1321,12 +1340,13 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   // (the pipelined LDS-DMA form has no staging registers: wide rows can take deeper tiles too -> fragment prefetch across
   //  blocks, fewer barriers)
   constexpr bool DMA_FORM = Traits<T>::ES == 2 && !BIAS;
-  constexpr int BMQ = (D * Traits<T>::ES >= 192) ? (DMA_FORM ? kDkvBmqWide : 32) : (NW == 8 ? kDkvBmq8 : 64);
+  // (lean form: 64-row query tiles; 32 at 256-byte rows, where two blocks' fragments do not fit the 256 registers)
+  constexpr int BMQ = LEAN ? (D * Traits<T>::ES < 256 ? 64 : 32) : (D * Traits<T>::ES >= 192) ? (DMA_FORM ? kDkvBmqWide : 32) : (NW == 8 ? kDkvBmq8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
-  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
-  auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS>;
+  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
+  auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
@@ -1337,6 +1357,11 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
+  } else if constexpr (Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES <= 256) {
+    // lean form (two waves per SIMD, V fragments from the LDS) where an 8-wave workgroup per CU still covers the chip; smaller grids
+    // keep the one-wave pipelined form.  (Two 4-wave workgroups per CU would do as well, but a grid with >= 448 of those always has
+    // >= 224 of the 8-wave ones.)
+    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8, true>(p, s);
   }
   return launch_dkv_nw<T, D, BIAS, 4>(p, s);
 }

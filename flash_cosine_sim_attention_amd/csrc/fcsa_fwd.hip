@@ -1110,17 +1110,15 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   } else if constexpr (fwd_lean<T, D, BIAS>()) {
-    // the lean form needs its partner wave: one 8-wave workgroup per CU, or enough 4-wave workgroups for two per CU
+    // the lean form needs its partner wave: one 8-wave workgroup per CU (a grid with two 4-wave workgroups per CU always has that)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
-    const int MT4 = (p.N + 127) / 128;
-    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= 448) return launch_fwd_nw<T, D, BIAS, 4, false, true>(p, s);
   }
   return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
 }
 
 template <typename T, int D>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
-  if constexpr (Traits<T>::ES == 2 && D <= 96) {       // D = 128: the pipeline state does not fit 512 registers
+  if constexpr (Traits<T>::ES == 2 && D <= 64) {       // (D = 96 / 128 take the lean two-wave kernel, see use_wide_fwd)
     if (p.bias == nullptr && !p.dyn && p.splits <= 1 && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
   }
   return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);

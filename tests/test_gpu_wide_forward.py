@@ -1,8 +1,9 @@
 """Parity of the WIDE forward kernel (64 query rows per wave, rotating MFMA / softmax pipeline; fcsa_fwd.hip fwd2_kernel).
 
 launch_forward picks it when the 256-row workgroups cover the chip (>= 224 of them) and
-  * not causal and dim_head >= 32, or
-  * causal and (dim_head == 96 and N >= 2048, or N >= 8192).
+  * not causal and dim_head in (32, 64), or
+  * causal and dim_head <= 64 and N >= 8192
+(dim_head 96 went to the lean two-wave 32-row kernel in round 3; its cases below stay as parity cases of that kernel).
 The shapes below are chosen to land on it through the normal dispatch:
   * many small heads (batch*heads = 224+), checked against the float64 oracle elementwise with the stated tolerances,
   * the long causal shapes, checked on (batch, head) slices against a float32 PyTorch evaluation on the GPU
@@ -47,8 +48,29 @@ WIDE_SMALL = [
 
 @pytest.mark.parametrize("B,H,N,M,D,dtype,use_mask,groups,scale", WIDE_SMALL)
 def test_wide_forward_matches_oracle(B, H, N, M, D, dtype, use_mask, groups, scale):
-    assert B * H * ((N + 255) // 256) >= 224, "shape would not dispatch to the wide kernel"
+    assert B * H * ((N + 255) // 256) >= 224, "shape would not dispatch to the wide (D <= 64) / lean (D = 96) kernel"
     _many_heads_vs_oracle(B, H, N, M, D, dtype, use_mask, groups, scale, causal=False)
+
+
+# Round 3: 16-bit D = 96 / 128 on grids that cover the chip with 8-wave workgroups run the LEAN forms -- forward (no cross-block
+# prefetch), dQ (4-wave workgroups, two per CU) and dK/dV (V fragments from an LDS copy of the workgroup's keys), all at two waves
+# per SIMD.  Same check as above: forward on five (batch, head) pairs and all gradients of one pair against the float64 oracle.
+LEAN_FORMS = [
+    # B, H, N,   M,   D,   dtype,          mask,  groups, scale, causal
+    (8, 28, 300, 300, 128, torch.bfloat16, False, 1, 8, True),
+    (8, 28, 300, 333, 128, torch.float16, True, 1, 8, False),     # ragged M, key padding mask, one batch element without keys
+    (7, 32, 260, 300, 96, torch.bfloat16, False, 3, 6, True),      # M > N: causal offset; grouped l2norm (group size 32)
+    (4, 60, 384, 384, 128, torch.float16, False, 8, 1, True),      # C5's head shape: groups = 8, scale 1
+    (15, 16, 520, 520, 128, torch.bfloat16, False, 1, 8, False),   # 240 heads x 3 row tiles, non-causal
+    (4, 60, 256, 129, 96, torch.float16, True, 1, 8, False),       # tail key tile of 1 key
+]
+
+
+@pytest.mark.parametrize("B,H,N,M,D,dtype,use_mask,groups,scale,causal", LEAN_FORMS)
+def test_lean_two_wave_forms_match_oracle(B, H, N, M, D, dtype, use_mask, groups, scale, causal):
+    MT = (N + 255) // 256
+    assert B * H * ((MT + 1) // 2 if causal else MT) >= 224, "shape would not dispatch to the 8-wave (lean) kernels"
+    _many_heads_vs_oracle(B, H, N, M, D, dtype, use_mask, groups, scale, causal=causal)
 
 
 # Causal with many small heads: the narrow kernels in their 8-waves-per-workgroup form (forward, dQ, dK/dV), which
@@ -127,7 +149,7 @@ WIDE_CAUSAL = [
 def test_wide_forward_causal_vs_f32_slices(B, H, N, M, D, dtype):
     import flash_cosine_sim_attention_amd as F
     MT = (N + 255) // 256
-    assert B * H * ((MT + 1) // 2) >= 224, "shape would not dispatch to the wide kernel"
+    assert B * H * ((MT + 1) // 2) >= 224, "shape would not dispatch to the wide (D <= 64) / lean (D = 96) kernel"
     q, k, v = _inputs(B, H, N, M, D, dtype, seed=N + D)
     o = F.flash_cosine_sim_attention(q, k, v, causal=True)
     assert torch.isfinite(o).all()
