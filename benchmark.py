@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--dtypes", default="float32,float16,bfloat16")
     ap.add_argument("--json", default=None, help="also write the table as JSON to this path")
     ap.add_argument("--seq-lens", type=int, nargs="+", default=list(SEQ_LENS), help="sequence lengths (default: the reference's sweep)")
+    ap.add_argument("--dim-head", type=int, default=64, help="head dimension (16, 32, 64, 96, 128; the reference's sweep uses 64)")
+    ap.add_argument("--no-baseline", default=False, action="store_true", help="skip the plain PyTorch composite column (dims sweep)")
     ap.add_argument("--hip-graph", default=False, action="store_true",
                     help="extra column: the fused op's window captured once in a HIP graph (torch.cuda.graph) and replayed -- what a "
                          "launch-bound caller (short sequences) gets by capturing its step")
@@ -101,20 +103,21 @@ def main():
     assert not (args.only_forwards and args.only_backwards)
     assert not (args.causal and args.mask_prob > 0), "mask should not be given if causal"
     backwards = not args.only_forwards
+    dim = args.dim_head
     rows = []
     for name in args.dtypes.split(","):
         dtype = getattr(torch, name)
         print("-" * 100)
-        print(f"{name}\t\tbatch: {BATCH}\theads: {HEADS}\tdim {DIM}\t"
+        print(f"{name}\t\tbatch: {BATCH}\theads: {HEADS}\tdim {dim}\t"
               f"{'causal ' if args.causal else ''}{'mask-prob %.2f ' % args.mask_prob if args.mask_prob else ''}"
               f"{'forward' if args.only_forwards else 'backward' if args.only_backwards else 'forward+backward'}")
         print("-" * 100)
         # one untimed call per dtype: the first launch of a kernel instantiation loads its code object (tens of ms)
-        w = torch.randn(BATCH, HEADS, 256, DIM, dtype=dtype, device="cuda", requires_grad=True)
+        w = torch.randn(BATCH, HEADS, 256, dim, dtype=dtype, device="cuda", requires_grad=True)
         flash_cosine_sim_attention(w, w, w, causal=args.causal).sum().backward()
         torch.cuda.synchronize()
         for seq in args.seq_lens:
-            q, k, v = (torch.randn(BATCH, HEADS, seq, DIM, dtype=dtype, device="cuda").requires_grad_(backwards) for _ in range(3))
+            q, k, v = (torch.randn(BATCH, HEADS, seq, dim, dtype=dtype, device="cuda").requires_grad_(backwards) for _ in range(3))
             mask = None
             if args.mask_prob > 0:
                 mask = torch.zeros((BATCH, seq), device="cuda").uniform_(0, 1) > args.mask_prob
@@ -139,7 +142,7 @@ def main():
             t_fused = timed(fused, args.num_times, backwards, args.only_backwards)
             t_graph = graph_replay_ms(fused, zero, backwards, args.num_times) if args.hip_graph and not args.only_backwards else None
             try:
-                t_base = timed(baseline, args.num_times, backwards, args.only_backwards)
+                t_base = None if args.no_baseline else timed(baseline, args.num_times, backwards, args.only_backwards)
             except torch.OutOfMemoryError:
                 torch.cuda.empty_cache()
                 t_base = None
@@ -149,10 +152,10 @@ def main():
                 t_sdpa = None
             frac = (seq + 1) / (2.0 * seq) if args.causal else 1.0
             mult = 4 if args.only_forwards else 10 if args.only_backwards else 14
-            tflops = mult * BATCH * HEADS * seq * seq * DIM * frac / (t_fused * 1e-3) / 1e12
+            tflops = mult * BATCH * HEADS * seq * seq * dim * frac / (t_fused * 1e-3) / 1e12
             slower = t_fused / t_base if t_base else 0.0
             print(f"seq_len: {seq}\tslower: {slower:.2f}x\tkernel: {t_fused:.3f}ms\tbaseline: "
-                  f"{'oom' if t_base is None else '%.3fms' % t_base}\t{tflops:7.1f} TFLOP/s\tsdpa: "
+                  f"{('skipped' if args.no_baseline else 'oom') if t_base is None else '%.3fms' % t_base}\t{tflops:7.1f} TFLOP/s\tsdpa: "
                   f"{'n/a' if t_sdpa is None else '%.3fms' % t_sdpa}" + ("" if t_graph is None else f"\thip-graph replay: {t_graph:.3f}ms"))
             rows.append(dict(dtype=name, seq_len=seq, kernel_ms=t_fused, baseline_ms=t_base, sdpa_ms=t_sdpa, tflops=tflops, graph_ms=t_graph))
             del q, k, v
