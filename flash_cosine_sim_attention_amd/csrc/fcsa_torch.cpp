@@ -221,6 +221,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> backward(const Tensor& d_out, const T
   const auto opt = q.options();
   Tensor o4 = prep(o.dim() == 3 ? o.unsqueeze(1) : o);
   Tensor do4 = d_out.dim() == 3 ? d_out.unsqueeze(1) : d_out;
+  // A broadcast gradient (`out.sum().backward()`, the reference's own timing protocol, benchmark.py:46-48: one scalar expanded with
+  // all strides 0) is not materialised at [B,H,N,D]: one contiguous feature row is, and the kernels read it with a row pitch of 0.
+  bool broadcast = do4.numel() > 0;
+  for (int64_t d = 0; d < do4.dim(); ++d) broadcast = broadcast && (do4.stride(d) == 0 || do4.size(d) == 1);
+  if (broadcast && do4.dim() == 4) {
+    Tensor row = do4.as_strided({do4.size(3)}, {0}).to(q.scalar_type()).contiguous();                  // [D], a D-element copy kernel
+    do4 = row.as_strided(do4.sizes(), {0, 0, 0, 1});
+  }
   if (do4.scalar_type() != q.scalar_type()) do4 = do4.to(q.scalar_type());
   do4 = prep(do4);
   TORCH_CHECK_VALUE(do4.sizes() == o4.sizes(), "d_out must have the shape of the output");
