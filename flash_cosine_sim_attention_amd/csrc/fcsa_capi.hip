@@ -142,11 +142,15 @@ struct BwdLayout {
 // Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
 // workgroups for 256 CUs), the problem is not causal and every split keeps >= 512 keys.  Mirrors forward_splits: C4 (1 x 8 heads x
 // 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  The ONE definition both the workspace size and the launch use.
+// Target: the split kernels are the 4-wave (128-row) forms; where those run two waves per SIMD (rows <= 128 bytes) a CU wants TWO
+// workgroups, i.e. 512 on the chip, else 256.  (Round 2 aimed at 256 throughout: C4 ran its forward and dQ at half occupancy.)
+int split_target(const fcsa_problem& p) { return elem_size(p.dtype) * p.dim_head <= 128 ? 512 : 256; }
 int backward_dq_splits(const fcsa_problem& p) {
   if (p.causal) return 1;
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
-  if (wgs <= 0 || wgs >= 128) return 1;
-  int64_t s = (256 + wgs - 1) / wgs;
+  const int target = split_target(p);
+  if (wgs <= 0 || wgs >= target / 2) return 1;
+  int64_t s = (target + wgs - 1) / wgs;
   if (s > 16) s = 16;
   if (s > p.k_len / 512) s = p.k_len / 512;
   return s >= 2 ? (int)s : 1;
@@ -284,8 +288,9 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
 static int forward_splits(const fcsa_problem& p) {
   if (p.causal || dynamic_shift(p)) return 1;
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
-  if (wgs <= 0 || wgs >= 128) return 1;
-  int64_t s = (256 + wgs - 1) / wgs;
+  const int target = split_target(p);
+  if (wgs <= 0 || wgs >= target / 2) return 1;
+  int64_t s = (target + wgs - 1) / wgs;
   if (s > 16) s = 16;
   if (s > p.k_len / 512) s = p.k_len / 512;
   return s >= 2 ? (int)s : 1;

@@ -133,9 +133,10 @@ def test_backward_workspace_single_head_non_causal_stays_small(lib):
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(64 * 8192 * 4)
     p = _problem(batch=64, heads=1, kv_heads=1, q_len=8192, k_len=8192, dim_head=128, dtype=2, l2norm_qk=1, bias_batch_dim=1)
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(64 * 8192 * 4)
-    # a grid that cannot fill the chip still gets its split slabs: C4 = 8 heads x 8 row tiles of 128 -> 4 splits
+    # a grid that cannot fill the chip still gets its split slabs: C4 = 8 heads x 8 row tiles of 128 -> 8 splits (512 workgroups:
+    # two per CU for the two-waves-per-SIMD kernels of 128-byte rows)
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64, dtype=1, l2norm_qk=1)
-    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 1024 * 4) + al(4 * 8 * 1024 * 64 * 4)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 1024 * 4) + al(8 * 8 * 1024 * 64 * 4)
 
 
 def test_forward_needs_qn(lib):
@@ -163,8 +164,8 @@ def test_scale_range(lib):
 def test_forward_workspace_formula(lib):
     # split-key forward: only non-causal problems whose 128-row tiles cannot fill the chip, with >= 1024 keys
     al = lambda x: (x + 255) // 256 * 256
-    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64)      # C4: 64 row tiles -> 4 splits
-    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(4 * 8 * 1024 * 64 * 4) + al(4 * 8 * 1024 * 4)
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64)      # C4: 64 row tiles -> 8 splits (512 workgroups)
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(8 * 8 * 1024 * 64 * 4) + al(8 * 8 * 1024 * 4)
     p = _problem(batch=4, heads=8, kv_heads=8, q_len=1024, k_len=1024, dim_head=64)      # C2: 256 row tiles
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64, causal=1)
