@@ -977,8 +977,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
   // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
-  // Q / dO tiles by LDS-DMA for every 16-bit form (round 3: also with bias -- the plain tile body reads them like the lean form does)
-  constexpr bool DMA = Traits<T>::ES == 2 && (BMQ * G::ROWB) % 1024 == 0;
+  constexpr bool DMA = (PIPE || LEAN) && (BMQ * G::ROWB) % 1024 == 0;
   typedef DkvLds<T, D, NW, BMQ, BIAS, LEAN> LDS;
   constexpr bool SEP = LDS::SEP;      // see bwd_dq_kernel: the next pass is requested from inside the epilogue of the current one
   Stager<T, D, BMQ, NT> sq, sdo;
