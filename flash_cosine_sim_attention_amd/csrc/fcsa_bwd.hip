@@ -17,7 +17,7 @@
 //                    Writes dk / dv per (batch, q-head); with single-headed K/V f32 slabs are
 //                    reduced over heads by the finalize kernel (fcsa_norm.hip) instead of the
 //                    reference's f32 atomics (cu:1613-1619).
-// Both kernels finish the l2norm backward in their epilogue (store_row_tile_l2norm_bwd) when the group size allows,
+// Both kernels finish the l2norm backward in their epilogue (RowEpilogue::finish, through the LDS) when the group size allows,
 // pair causal tiles (constant work per workgroup) and run with 4 or 8 waves per workgroup (8: tiles staged once per CU;
 // dkv then stages 128-row query tiles, half the barriers).
 //

@@ -195,10 +195,6 @@ template <typename T> struct BiasBlock {
 #pragma unroll
     for (int v = 0; v < NV; ++v) *reinterpret_cast<u32x4*>(dst + 16 * v) = raw[v];
   }
-  // bias[query 32-block row q][this lane's key]
-  static FCSA_DEV float value(const char* scr, int q, int lane) {
-    return (float)*reinterpret_cast<const typename Traits<T>::elem*>(scr + q * PITCH + (lane & 31) * ES);
-  }
 };
 
 // row index (0..31) of accumulator register r for lane half hi
@@ -521,75 +517,6 @@ FCSA_DEV void store_row_tile(char* row, const f32x16 (&acc)[TileGeom<D, Traits<T
 
 // sum of a per-lane value over the two half-waves (lane ^ 32)
 FCSA_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32, 64); }
-
-// Fused l2norm backward + store of a C-layout gradient tile (epilogue of the dQ / dKV kernels).
-// The lane pair (row, hi = 0/1) holds the whole gradient row g = mul * acc w.r.t. the NORMALISED vector xh;
-// per group G of the row:  dx = r * (g - xh <g, xh>_G)   (r = 1/max(||x_G||, eps); dx = g * r where the norm was
-// clamped).  xh = xn_scale * xn is re-read from the saved normalised tensor (L2-resident), r from the saved
-// inverse norms.  Groups are (8 << lgm) features wide, lgm = log2(group size / 8): the 8-feature blocks
-// (db, rq) of the C layout never straddle a group.  Replaces an f32 slab round trip + a finalize launch.
-template <typename T, int D>
-FCSA_DEV void store_row_tile_l2norm_bwd(char* out_row, const f32x16 (&acc)[TileGeom<D, Traits<T>::ES>::DB], float mul, int hi,
-                                        const char* xn_row, float xn_scale, const float* inv_norm_row, int lgm, float eps) {
-  typedef Traits<T> TR;
-  constexpr int NB = D / 8;
-  // xh is read twice (dot pass, output pass) instead of being kept: the accumulators of the other gradient are
-  // still live at this point and a second L2 read is cheaper than spilling
-  auto load_xh = [&](int bq, float (&xh)[4]) {
-    const int d0 = 32 * (bq >> 2) + 8 * (bq & 3) + 4 * hi;
-    if constexpr (TR::ES == 4) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(xn_row + d0 * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xh[e] = x[e] * xn_scale;
-    } else {
-      const u32x2 x = *reinterpret_cast<const u32x2*>(xn_row + d0 * 2);
-      xh[0] = TR::lo(x[0]) * xn_scale; xh[1] = TR::hi(x[0]) * xn_scale;
-      xh[2] = TR::lo(x[1]) * xn_scale; xh[3] = TR::hi(x[1]) * xn_scale;
-    }
-  };
-  float bd[NB];
-#pragma unroll
-  for (int bq = 0; bq < NB; ++bq) {
-    float xh[4];
-    load_xh(bq, xh);
-    float pd = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pd += acc[bq >> 2][4 * (bq & 3) + e] * mul * xh[e];
-    bd[bq] = xhalf_sum(pd);
-  }
-#pragma unroll
-  for (int bq = 0; bq < NB; ++bq) {
-    const int db = bq >> 2, rq = bq & 3;
-    const int d0 = 32 * db + 8 * rq + 4 * hi;
-    const int gid = bq >> lgm;
-    float dot = 0.f;
-    if (((NB - 1) >> lgm) == 0) {      // one group (groups = 1): plain sum, wave-uniform branch
-#pragma unroll
-      for (int b2 = 0; b2 < NB; ++b2) dot += bd[b2];
-    } else {
-#pragma unroll
-      for (int b2 = 0; b2 < NB; ++b2) dot += ((b2 >> lgm) == gid) ? bd[b2] : 0.f;
-    }
-    const float r = inv_norm_row[gid];
-    const bool clamped = r >= 1.f / eps;
-    float xh[4], o4[4];
-    load_xh(bq, xh);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = acc[db][4 * rq + e] * mul;
-      o4[e] = clamped ? g * r : r * (g - xh[e] * dot);
-    }
-    if constexpr (TR::ES == 4) {
-      f32x4 v = {o4[0], o4[1], o4[2], o4[3]};
-      *reinterpret_cast<f32x4*>(out_row + d0 * 4) = v;
-    } else {
-      u32x2 v;
-      v[0] = TR::pack2(o4[0], o4[1]);
-      v[1] = TR::pack2(o4[2], o4[3]);
-      *reinterpret_cast<u32x2*>(out_row + d0 * 2) = v;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Row epilogue through LDS.  The C layout gives a lane 4 consecutive features of ITS row per (db, rq): stored directly that is
