@@ -1341,7 +1341,9 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   //  blocks, fewer barriers)
   constexpr bool DMA_FORM = Traits<T>::ES == 2 && !BIAS;
   // (lean form: 64-row query tiles; 32 at 256-byte rows, where two blocks' fragments do not fit the 256 registers)
-  constexpr int BMQ = LEAN ? (D * Traits<T>::ES < 256 ? 64 : 32) : (D * Traits<T>::ES >= 192) ? (DMA_FORM ? kDkvBmqWide : 32) : (NW == 8 ? kDkvBmq8 : 64);
+  // (64-row tiles at D = 128 measured +8 ... +15 % time: two blocks' fragments do not fit, the reloads sit in the tile loop)
+  constexpr int LEAN_BMQ = D * Traits<T>::ES < 256 ? 64 : 32;
+  constexpr int BMQ = LEAN ? LEAN_BMQ : (D * Traits<T>::ES >= 192) ? (DMA_FORM ? kDkvBmqWide : 32) : (NW == 8 ? kDkvBmq8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
