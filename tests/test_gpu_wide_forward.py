@@ -161,3 +161,33 @@ def test_wide_forward_causal_vs_f32_slices(B, H, N, M, D, dtype):
     # rows of P sum to one (every row has at least one valid key when M >= N)
     o1 = F.flash_cosine_sim_attention(q, k, torch.ones_like(v), causal=True)
     assert (o1.float() - 1).abs().max().item() <= (2e-3 if dtype == torch.float16 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype,D,groups", [(torch.bfloat16, 128, 8), (torch.float16, 96, 1)])
+def test_lean_forms_with_single_headed_kv(dtype, D, groups):
+    """Single-headed K/V (head stride 0) through the lean kernels of a chip-covering grid: the forward must equal, bit for bit, the
+    same call with K / V expanded to every head, and dk / dv must equal the head sums of that call's gradients (the f32 slabs + finalize
+    against 60 separately rounded 16-bit gradients: compared at the 16-bit rounding of the summands)."""
+    import flash_cosine_sim_attention_amd as F
+    B, H, N = 4, 60, 300
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn((B, H, N, D), device="cuda", dtype=dtype, generator=g).requires_grad_()
+    k1 = torch.randn((B, N, D), device="cuda", dtype=dtype, generator=g).requires_grad_()
+    v1 = torch.randn((B, N, D), device="cuda", dtype=dtype, generator=g).requires_grad_()
+    do = torch.randn((B, H, N, D), device="cuda", dtype=dtype, generator=g)
+    kw = dict(causal=True, groups=groups, scale=1.0 if groups > 1 else 8.0)
+    o1 = F.flash_cosine_sim_attention(q, k1, v1, **kw)
+    o1.backward(do)
+    dq1, dk1, dv1 = q.grad.clone(), k1.grad.clone(), v1.grad.clone()
+    q.grad = None
+    kf = k1.detach()[:, None].expand(B, H, N, D).contiguous().requires_grad_()
+    vf = v1.detach()[:, None].expand(B, H, N, D).contiguous().requires_grad_()
+    of = F.flash_cosine_sim_attention(q, kf, vf, **kw)
+    of.backward(do)
+    assert torch.equal(o1, of)
+    assert torch.equal(dq1, q.grad)
+    for name, single, full in (("dk", dk1, kf.grad), ("dv", dv1, vf.grad)):
+        ref = full.float().sum(1)
+        scale_ = full.float().abs().sum(1).max().item()          # rounding of the 60 summands, each to 2^-9 (bf16) / 2^-11 (f16) relative
+        err = (single.float() - ref).abs().max().item()
+        assert err <= (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10) * scale_, f"{name}: {err:.3e} vs scale {scale_:.3e}"
