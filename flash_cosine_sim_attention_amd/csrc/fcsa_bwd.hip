@@ -983,14 +983,12 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   Stager<T, D, BMQ, NT> sq, sdo;
   typedef DmaStager<T, D, DMA ? BMQ : 1024, NW> DS;
   DS dq_, ddo_;
-  DmaStager<T, D, LEAN ? BNK : 1024, NW> dvown_;      // LEAN: the workgroup's own V rows, staged once per pass
   typename DS::Stream stq, stdo;      // Q / dO walked tile by tile from the pass's first tile (DMA form)
   uint32_t q_step = 0, do_step = 0, lds0 = 0;
   bool far = false;
   if constexpr (DMA) {
     dq_.init(p.q.sn, wave, lane);
     ddo_.init(p.d_out.sn, wave, lane);
-    if constexpr (LEAN) dvown_.init(p.v.sn, wave, lane);
     q_step = (uint32_t)(BMQ * p.q.sn);
     do_step = (uint32_t)(BMQ * p.d_out.sn);
     far = BMQ * p.q.sn > (int64_t)DS::REBASE || BMQ * p.d_out.sn > (int64_t)DS::REBASE;
@@ -1052,6 +1050,8 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       }
     }
     if constexpr (LEAN) {      // the V rows of this workgroup's keys -> LDS (rows past M are zero-filled by the descriptor's range check)
+      DmaStager<T, D, BNK, NW> dvown_;      // (set up here, once per pass, from an opaque lane id: nothing of it lives across the tile loops)
+      dvown_.init(p.v.sn, wave, opaque(lane));
       dvown_.issue(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)n0_ * p.v.sn, p.v.sn, p.M - n0_, smem + LDS::VOWN, wave);
     }
     const int ln = opaque(lane), hi_ = ln >> 5;
@@ -1324,8 +1324,9 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges
   if constexpr (NARROW) {
     if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
-  } else if constexpr (dq_can_two_waves<T, D>()) {
+  } else if constexpr (dq_can_two_waves<T, D>() && !BIAS) {
     // two waves per SIMD need two 128-row workgroups on every CU; smaller grids keep the one-wave (pipelined) form
+    // (bias launches keep the one-wave form too: their two-wave instantiation spills 17 registers and was never measured ahead)
     const int MT4 = (p.N + 127) / 128;
     if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= 448) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
   }
