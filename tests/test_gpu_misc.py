@@ -63,6 +63,11 @@ def test_benchmark_cli_smoke():
                           "--seq-lens", "128", "256", "--causal"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "128" in res.stdout and "256" in res.stdout
+    # round 3: head-dim sweeps (tools/dims_sweep.sh) use --dim-head / --no-baseline
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "benchmark.py"), "--num-times", "1", "--dtypes", "float16", "--seq-lens", "256",
+                          "--dim-head", "128", "--no-baseline", "--only-forwards"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "dim 128" in res.stdout and "skipped" in res.stdout
 
 
 def test_saved_tensors_are_tracked_by_autograd():
