@@ -30,7 +30,8 @@
 //   fwd_kernel<.., NW = 4 | 8, ..>  two 128-row workgroups per CU, or one 256-row workgroup when the grid still covers the chip
 //   fwd_kernel<.., DYN>             per-row exponent shift for logit ranges no constant shift can hold (first pass = row max)
 //   fwd_kernel, gridDim.y = splits  key range split over several workgroups + fwd_combine_kernel (grids that cannot fill the chip)
-//   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 96, 16 bit, no bias; see its header)
+//   fwd_kernel<.., LEAN>            16-bit D = 96 / 128 on chip-covering grids: no cross-block prefetch, 256 registers, two waves per SIMD
+//   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 64, 16 bit, no bias; see its header)
 #include <cstdlib>
 #include <type_traits>
 

@@ -11,9 +11,10 @@ Differences from the reference, all inside the boundary:
     (a missing libfcsa_hip.so raises ImportError).  CPU tensors take this package's own
     forward-only blockwise path (`cpu.py`), as they do in the reference (py:322-323).
 
-Limits (documented divergence): with l2norm_qk the logit range is +-scale*groups; the library
-refuses scale*groups > 87 (exp of the range leaves float32) where the reference kernel would
-overflow / zero rows silently.
+Logit range: with l2norm_qk the logits lie in +-|scale|*groups.  Inside the library's static exponent window (f16: <= 11,
+bf16 / f32: <= 75) the kernels use one constant shift like the reference (whose kernel overflows / zeroes rows at the far end of that
+range); beyond it the forward shifts every row by its own max logit and normalises exactly, like the reference's PyTorch
+plain_cosine_sim_attention.  There is no limit on scale (only float16 refuses |scale| * log2(e) > 60000).
 """
 from __future__ import annotations
 
@@ -132,7 +133,7 @@ def flash_cosine_sim_attention(q, k, v, mask=None, attn_bias=None, scale=8, grou
 
     GPU tensors: hand-written gfx950 kernels, forward and backward (gradients w.r.t. the raw q, k, v, attn_bias).
     CPU tensors: forward-only blockwise path (`cpu.attention_forward_cpu`), like the reference (py:322-323).
-    scale * groups must not exceed 87 when l2norm_qk is set (see the module docstring)."""
+    Any finite scale runs (see the module docstring for the exponent-shift regimes)."""
     if q.device.type == "cpu":
         return _cpu.attention_forward_cpu(q, k, v, mask=mask, attn_bias=attn_bias, scale=scale, groups=groups, causal=causal,
                                           l2norm_qk=l2norm_qk, attn_bias_batch_dim=attn_bias_batch_dim)
