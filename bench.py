@@ -339,7 +339,7 @@ def main():
 
     # ---- the other configs, the reference's timing protocol, host-bound sizes (rank 0; ~2 s) -----------------------------
     configs = ref_proto = small = None
-    if rank == 0 and not args.no_extra_configs:
+    if rank == 0 and world == 1 and not args.no_extra_configs:      # (N > 1 runs report the headline only: the other ranks are waiting)
         configs = {}
         for name, c in EXTRA_CONFIGS.items():
             try:
