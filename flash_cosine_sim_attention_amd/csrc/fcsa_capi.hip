@@ -108,15 +108,19 @@ fcsa::View contiguous_view(void* p, int64_t heads, int64_t len, int64_t d, int e
 // for the backward is then log2(1 / sum_j exp(S_ij)) -- the value the backward kernels seed their S accumulators with anyway --
 // so nothing ever holds exp() of the full logit range and there is no limit on scale * groups.
 constexpr float kStaticTop = 65.f, kStaticBottom = 85.f;      // exp(s - shift) stays within [e^-85, e^65] (bf16 / f32)
-bool dynamic_shift(const fcsa_problem& p) {
+// An additive bias makes the exponent unbounded.  bf16 / f32 absorb it inside the static window (e^-85 ... e^65 leaves +-20 around any
+// shift; a strongly negative bias underflows to an exact 0 weight).  f16 does not: its static shift puts the largest logit at e^10 of a
+// 65504 range, so a bias of +1.1 on such a logit overflowed P~ to inf (found by an exploratory fuzz seed in round 3: f16, scale 1, bias
+// ~ N(0, 0.5)).  f16 problems WITH a bias therefore always take the per-row-max form (which includes the bias in the max).
+bool dynamic_shift(const fcsa_problem& p, bool has_bias) {
   if (!p.l2norm_qk) return false;
   const float bound = fabsf(p.scale) * (float)p.groups;
-  return p.dtype == FCSA_F16 ? bound > 11.f : 2.f * bound > kStaticTop + kStaticBottom;
+  return p.dtype == FCSA_F16 ? (has_bias || bound > 11.f) : 2.f * bound > kStaticTop + kStaticBottom;
 }
 
-float exponent_shift(const fcsa_problem& p) {
+float exponent_shift(const fcsa_problem& p, bool has_bias) {
   if (!p.l2norm_qk) return p.scale;
-  if (dynamic_shift(p)) return 0.f;
+  if (dynamic_shift(p, has_bias)) return 0.f;
   const float bound = fabsf(p.scale) * (float)p.groups;
   if (p.dtype == FCSA_F16) return bound - 10.f;
   const float lo = bound - kStaticTop, hi = kStaticBottom - bound;
@@ -125,9 +129,9 @@ float exponent_shift(const fcsa_problem& p) {
 
 // Row-sum clamp: the reference clamps l at 1e-10 (cu:83, cu:1239) with shift = scale; with another shift the
 // same clamp in the reference's units is 1e-10 * exp(scale - shift) (kept inside f32's normal range).
-float rowsum_eps(const fcsa_problem& p) {
-  if (dynamic_shift(p)) return 1e-30f;          // row sums are >= 1 there (the max element contributes exp(0))
-  float e = 1e-10f * expf(p.scale - exponent_shift(p));
+float rowsum_eps(const fcsa_problem& p, bool has_bias) {
+  if (dynamic_shift(p, has_bias)) return 1e-30f;          // row sums are >= 1 there (the max element contributes exp(0))
+  float e = 1e-10f * expf(p.scale - exponent_shift(p, has_bias));
   if (!(e > 1e-37f)) e = 1e-37f;
   if (e > 1e30f) e = 1e30f;
   return e;
@@ -287,7 +291,7 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
 // chip (< 128 workgroups for 256 CUs), the problem is not causal (key ranges of a causal row tile are short and uneven),
 // the static exponent shift applies (partials with a common shift add up exactly) and every split keeps >= 512 keys.
 static int forward_splits(const fcsa_problem& p) {
-  if (p.causal || dynamic_shift(p)) return 1;
+  if (p.causal || dynamic_shift(p, false)) return 1;      // (never called with a bias: fcsa_forward only splits bias-free problems)
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
   const int target = split_target(p);
   if (wgs <= 0 || wgs >= target / 2) return 1;
@@ -357,15 +361,16 @@ int fcsa_forward(const fcsa_forward_args* a) {
   fp.B = p.batch; fp.H = p.heads; fp.N = p.q_len; fp.M = p.k_len;
   fp.causal = p.causal; fp.bias_batch = p.bias_batch_dim;
   fp.c1 = p.scale * kLog2e;
-  fp.c2 = exponent_shift(p) * kLog2e;
+  const bool has_bias = a->attn_bias != nullptr;
+  fp.c2 = exponent_shift(p, has_bias) * kLog2e;
   fp.bias_c = kLog2e;
-  fp.l_eps = rowsum_eps(p);
+  fp.l_eps = rowsum_eps(p, has_bias);
   fp.q_scaled = p.l2norm_qk ? 1 : 0;
   fp.q_raw = fuse_q ? 1 : 0;
   fp.qn_out = fuse_q ? static_cast<char*>(a->norm.qn) : nullptr;
   fp.rq_out = fuse_q ? a->norm.rq : nullptr;
   fp.G = p.groups; fp.lgm = fuse_q ? log2_blocks_per_group(p) : 0; fp.norm_eps = 1e-12f;
-  fp.dyn = dynamic_shift(p) ? 1 : 0;      // then inv_l holds log2 of the normaliser
+  fp.dyn = dynamic_shift(p, has_bias) ? 1 : 0;      // then inv_l holds log2 of the normaliser
   fp.splits = 1; fp.ws_o = nullptr; fp.ws_l = nullptr;
   if (a->workspace != nullptr && a->attn_bias == nullptr) {
     const int sp = forward_splits(p);
@@ -460,8 +465,8 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.B = p.batch; bp.H = p.heads; bp.N = p.q_len; bp.M = p.k_len;
   bp.causal = p.causal; bp.bias_batch = p.bias_batch_dim;
   bp.c1 = p.scale * kLog2e;
-  bp.c2 = exponent_shift(p) * kLog2e;
-  bp.invl_log2 = dynamic_shift(p) ? 1 : 0;
+  bp.c2 = exponent_shift(p, a->attn_bias != nullptr) * kLog2e;
+  bp.invl_log2 = dynamic_shift(p, a->attn_bias != nullptr) ? 1 : 0;
   bp.bias_c = kLog2e;
   bp.scale = p.scale;
   bp.q_scaled = p.l2norm_qk ? 1 : 0;

@@ -508,13 +508,14 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(kfr[kk], qf[kk], s);
+        float bv[16];
+        if constexpr (BIAS)      // same wide loads as the main loop (float16 problems with a bias always come through here)
+          load_bias_block<T>(bv, bias_row, j0 + 32 * jb + 4 * fa.hi, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0,
+                             p.bias_c, (p.M & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, fa.hi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float x = s[r];
-          if constexpr (BIAS) {
-            const int j = min(j0 + 32 * jb + 4 * fa.hi + crow(r, 0), p.M - 1);
-            x += (float)reinterpret_cast<const typename TR::elem*>(bias_row)[j] * p.bias_c;
-          }
+          if constexpr (BIAS) x += bv[r];
           m2 = ((w >> crow(r, 0)) & 1u) ? fmaxf(m2, x) : m2;
         }
       }

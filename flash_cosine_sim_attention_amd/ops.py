@@ -11,7 +11,7 @@ Differences from the reference, all inside the boundary:
     (a missing libfcsa_hip.so raises ImportError).  CPU tensors take this package's own
     forward-only blockwise path (`cpu.py`), as they do in the reference (py:322-323).
 
-Logit range: with l2norm_qk the logits lie in +-|scale|*groups.  Inside the library's static exponent window (f16: <= 11,
+Logit range: with l2norm_qk the logits lie in +-|scale|*groups.  Inside the library's static exponent window (f16: <= 11 and no attn_bias,
 bf16 / f32: <= 75) the kernels use one constant shift like the reference (whose kernel overflows / zeroes rows at the far end of that
 range); beyond it the forward shifts every row by its own max logit and normalises exactly, like the reference's PyTorch
 plain_cosine_sim_attention.  There is no limit on scale (only float16 refuses |scale| * log2(e) > 60000).

@@ -57,8 +57,8 @@ def _npf(t):
     return t.detach().cpu().double().numpy()
 
 
-@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: c["id"])
-def test_random_config_matches_oracle(cfg):
+def evaluate(cfg):
+    """runs one configuration; yields (what, measured, limit) for the forward and every gradient (tools/fuzz_case.py prints them)"""
     import flash_cosine_sim_attention_amd as F
     dt = DT[cfg["dtype"]]
     B, H, N, M, D = cfg["B"], cfg["H"], cfg["N"], cfg["M"], cfg["D"]
@@ -83,7 +83,7 @@ def test_random_config_matches_oracle(cfg):
     do = torch.randn(o.shape, device="cuda", dtype=dt, generator=g)
     o.backward(do)
     torch.cuda.synchronize()
-    assert torch.isfinite(o).all()
+    yield "non-finite outputs", int((~torch.isfinite(o)).sum().item()), 0
 
     many = B * H >= 224
     if many and not cfg["single_kv"]:
@@ -94,7 +94,7 @@ def test_random_config_matches_oracle(cfg):
     # plain_cosine_sim_attention; the reference KERNEL's clamp max(l, 1e-10), taken in exp(S - scale) units, attenuates or
     # zeroes rows at such logit ranges (scale 70: every row).  The oracle restates that clamp, so switch it off there.
     bound = cfg["scale"] * cfg["groups"]
-    dyn = cfg["l2norm"] and (bound > 11 if cfg["dtype"] == "f16" else bound > 75)      # fcsa_capi.hip dynamic_shift
+    dyn = cfg["l2norm"] and ((bound > 11 or cfg["bias"]) if cfg["dtype"] == "f16" else bound > 75)      # fcsa_capi.hip dynamic_shift
     eps = 1e-300 if dyn else 1e-10
     atol, rtol = FWD_TOL[cfg["dtype"]]
     cond = max(1.0, cfg["scale"] * cfg["groups"] / 16.0) if cfg["dtype"] != "f32" and cfg["l2norm"] else 1.0
@@ -114,17 +114,27 @@ def test_random_config_matches_oracle(cfg):
         got = _npf(o)[sl_q]
         vmax = max(np.abs(vq).max(), 1e-6)
         excess = (np.abs(got - ro) - rtol * np.abs(ro)).max()
-        assert excess <= cond * atol * max(vmax, 1.0), f"{cfg} {pr}: forward excess {excess:.3e}"
+        yield f"{pr}: forward excess", excess, cond * atol * max(vmax, 1.0)
         grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, **okw)
         names = ["dq", "dk", "dv"] + (["d_bias"] if bias is not None else [])
         gots = [_npf(q.grad)[sl_q], _npf(k.grad)[sl_k] if not cfg["single_kv"] else _npf(k.grad),
                 _npf(v.grad)[sl_k] if not cfg["single_kv"] else _npf(v.grad)] + ([_npf(bias.grad)] if bias is not None else [])
         for name, gg, rr in zip(names, gots, grads):
-            # the floor keeps the ratio meaningful when the exact gradient is (nearly) zero, e.g. N = M = 1 where P == 1 and
-            # dS == P (dP - delta) == 0 exactly: the kernel then returns the f32 cancellation noise of dP - delta, ~eps * |dP| with
-            # |dP| ~ sqrt(D) (seen with an exploratory seed: 1e-6 per element for f32).  f32's 2e-5 needs the larger floor.
-            # (that noise enters dq / dk multiplied by `scale`: exploratory seed 11, N = M = 1, scale 10, f32: 2.3e-5 against the floor of scale 8)
-            floor = (5e-2 * max(1.0, cfg["scale"] / 8.0) if cfg["dtype"] == "f32" else 1e-3) * np.sqrt(rr.size)
-            rel = np.linalg.norm(gg - rr) / max(np.linalg.norm(rr), floor)
+            # the floor keeps the ratio meaningful when the exact gradient is (nearly) zero.  f32 additionally gets an ABSOLUTE
+            # allowance: where P == 1 (N = M = 1, or one unmasked key) dS == P (dP - delta) == 0 exactly and the kernel returns the f32
+            # cancellation noise of dP - delta, ~eps * |dP| with |dP| ~ sqrt(D), times `scale` on its way into dq / dk -- measured
+            # with exploratory seeds (11, 55, 77): 1e-6 ... 2.4e-6 * scale / 8 rms.  Against f32's 2e-5 no relative floor is both tight
+            # for real gradients and loose enough for that noise, so the noise is bounded on its own.
+            err = np.linalg.norm(gg - rr)
+            floor = (5e-2 if cfg["dtype"] == "f32" else 1e-3) * np.sqrt(rr.size)
+            if cfg["dtype"] == "f32" and np.linalg.norm(rr) < floor and err <= 6e-6 * max(1.0, cfg["scale"] / 8.0) * np.sqrt(rr.size):
+                continue
+            rel = err / max(np.linalg.norm(rr), floor)
             lim = cond * GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
-            assert rel <= lim, f"{cfg} {pr}: {name} rel-L2 {rel:.3e} > {lim}"
+            yield f"{pr}: {name} rel-L2", rel, lim
+
+
+@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: c["id"])
+def test_random_config_matches_oracle(cfg):
+    for what, got, lim in evaluate(cfg):
+        assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"
