@@ -111,7 +111,7 @@ constexpr float kStaticTop = 65.f, kStaticBottom = 85.f;      // exp(s - shift) 
 // An additive bias makes the exponent unbounded.  bf16 / f32 absorb it inside the static window (e^-85 ... e^65 leaves +-20 around any
 // shift; a strongly negative bias underflows to an exact 0 weight).  f16 does not: its static shift puts the largest logit at e^10 of a
 // 65504 range, so a bias of +1.1 on such a logit overflowed P~ to inf (found by an exploratory fuzz seed in round 3: f16, scale 1, bias
-// ~ N(0, 0.5)).  f16 problems WITH a bias therefore always take the per-row-max form (which includes the bias in the max).
+// ~ N(0, 0.5)).  f16 problems WITH a bias therefore always take the per-row-reference form (whose online max includes the bias).
 bool dynamic_shift(const fcsa_problem& p, bool has_bias) {
   if (!p.l2norm_qk) return false;
   const float bound = fabsf(p.scale) * (float)p.groups;

@@ -28,7 +28,7 @@
 //
 // Variants chosen by launch_forward (all parity-tested through the normal dispatch):
 //   fwd_kernel<.., NW = 4 | 8, ..>  two 128-row workgroups per CU, or one 256-row workgroup when the grid still covers the chip
-//   fwd_kernel<.., DYN>             per-row exponent shift for logit ranges no constant shift can hold (first pass = row max)
+//   fwd_kernel<.., DYN>             per-row exponent reference for logit ranges no constant shift can hold (kept online, one pass)
 //   fwd_kernel, gridDim.y = splits  key range split over several workgroups + fwd_combine_kernel (grids that cannot fill the chip)
 //   fwd_kernel<.., LEAN>            16-bit D = 96 / 128 on chip-covering grids: no cross-block prefetch, 256 registers, two waves per SIMD
 //   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 64, 16 bit, no bias; see its header)
@@ -61,10 +61,57 @@ template <typename T, int D, bool BIAS> constexpr bool fwd_lean() {
   return Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES > 128 && D * Traits<T>::ES <= 256;
 }
 
+// Per-row exponent reference of the DYN kernels, kept ONLINE (one pass over the keys).  `x` holds one block's exponents of this lane's
+// row (log2 units, relative to the row's current reference `mref`, masked positions at -inf).  The block is used as it is while its
+// largest exponent stays inside what the rounded P~ can hold (2^kTau); otherwise -- and at the row's first block with a valid key,
+// whatever its level -- the reference moves to the block's max: x -= d, and what the row has accumulated so far is rescaled by
+// 2^-d (per LANE: the C layout gives every lane its own row, so there is no broadcast).  The test is one wave-uniform branch per
+// block that is taken a handful of times per row tile; rows end with their max inside [0, kTau] of the reference, i.e. no weight
+// that matters is lost to the 16-bit exponent range whatever scale, groups or bias are.  (Rounds 1 - 2: a first pass over all K
+// tiles computed the row max -- +70 % forward time; the bias form read the bias twice.)
+template <typename T> constexpr float online_tau() { return std::is_same<T, F16>::value ? 10.f : 64.f; }
+
+FCSA_DEV float max16(const f32x16& x) {
+  float m = fmaxf(fmaxf(x[0], x[1]), x[2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, x[r]), x[r + 1]);      // (v_max3_f32)
+  return fmaxf(m, x[15]);
+}
+
+// bm: largest exponent of the block(s) about to be used, this lane's half of the row.  `relog(d)` re-expresses the logits that were
+// accumulated against the old reference (x -= d) and whatever was derived from them.
+template <typename T, int DB, typename Relog>
+FCSA_DEV void online_recentre(float bm, float& mref, float& rmax, f32x16 (&o)[DB], float& l, f32x16& lacc, Relog&& relog) {
+  {   // the lane pair of a row: v_permlane32_swap (VALU) -- __shfl_xor is a ds_bpermute round trip in front of the branch
+    const uint32_t bits = __builtin_bit_cast(uint32_t, bm);
+    const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+    bm = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+  }
+  const bool first = rmax == -INFINITY && bm > -INFINITY;
+  const bool move = first || bm > online_tau<T>();
+  if (__builtin_amdgcn_ballot_w64(move) != 0) {
+    const float d = move ? bm : 0.f;
+    // nothing is accumulated before the first valid key (and d may be far below zero there: 2^-d would overflow)
+    const float f = first ? 1.f : fast_exp2(-d);
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= f;
+    l *= f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] *= f;
+    mref += d;
+    rmax = first ? 0.f : rmax - d;
+    bm -= d;
+    relog(d);
+  }
+  rmax = fmaxf(rmax, bm);
+}
+
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
-template <typename T, bool MASKED, bool BIAS>
+template <typename T, int DB, bool MASKED, bool BIAS, bool ONL, typename Other>
 FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lacc, const FwdParams& p, uint32_t w,
-                                int jbase, const char* bias_row) {
+                                int jbase, const char* bias_row, float& mref, float& rmax, f32x16 (&o)[DB], Other&& other) {
   typedef Traits<T> TR;
   float bv[16];
   if constexpr (BIAS) {
@@ -73,14 +120,33 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
     load_bias_block<T>(bv, bias_row, jbase, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c,
                        (p.M & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, (jbase >> 2) & 1);
   }
+  if constexpr (ONL) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float x = s[r];                 // = c1 * qh.kh - c2 already: c1 rides on q, -c2 is the accumulator's initial value
-    if constexpr (BIAS) x += bv[r];
-    float e = fast_exp2(x);
-    if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
-    if constexpr (TR::ES == 4) l += e;
-    s[r] = e;
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (BIAS) s[r] += bv[r];
+      if constexpr (MASKED) s[r] = ((w >> crow(r, 0)) & 1u) ? s[r] : -INFINITY;      // 2^-inf == 0: the mask needs no second select
+    }
+    online_recentre<T, DB>(max16(s), mref, rmax, o, l, lacc, [&](float d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] -= d;
+      other(d);
+    });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = fast_exp2(s[r]);
+      if constexpr (TR::ES == 4) l += e;
+      s[r] = e;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float x = s[r];                 // = c1 * qh.kh - c2 already: c1 rides on q, -c2 is the accumulator's initial value
+      if constexpr (BIAS) x += bv[r];
+      float e = fast_exp2(x);
+      if constexpr (MASKED) e = ((w >> crow(r, 0)) & 1u) ? e : 0.f;
+      if constexpr (TR::ES == 4) l += e;
+      s[r] = e;
+    }
   }
   pb.prep(s);
   if constexpr (TR::ES == 2) {      // lacc[*][i] += sum over this block's 32 keys of the rounded P~
@@ -98,11 +164,12 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
 // next tile's fragments land during the PV products instead of being waited for at the top of the next tile
 // (phase timing of the previous structure: 690 of 2490 cycles per tile were spent there, right after the barrier,
 // with all four waves bursting their K reads at once).
-template <typename T, int D, bool MASKED, bool BIAS, bool LEAN, typename Mid>
+template <typename T, int D, bool MASKED, bool BIAS, bool LEAN, bool ONL, typename Mid>
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
-                       float& l, f32x16& lacc, const FwdParams& p, float c2row, uint64_t word, uint32_t ncm, int i, int j0, int diff,
+                       float& l, f32x16& lacc, const FwdParams& p, float& c2row, float& rmax, uint64_t word, uint32_t ncm, int i, int j0, int diff,
                        const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k, const char* kt) {
+
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;     // see fwd_kernel
@@ -141,11 +208,24 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
 #pragma unroll
       for (int db = 0; db < G::DB; ++db) { vf[db][0] = fa.tr_frag(vt, 32 * jb, db); vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db); }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ONL) {
+        if constexpr (MASKED) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float e = fast_exp2(s[r]);
-        if constexpr (MASKED) e = ((w[jb] >> crow(r, 0)) & 1u) ? e : 0.f;
-        s[r] = e;
+          for (int r = 0; r < 16; ++r) s[r] = ((w[jb] >> crow(r, 0)) & 1u) ? s[r] : -INFINITY;
+        }
+        online_recentre<T, G::DB>(max16(s), c2row, rmax, o, l, lacc, [&](float d) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] -= d;
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float e = fast_exp2(s[r]);
+          if constexpr (MASKED) e = ((w[jb] >> crow(r, 0)) & 1u) ? e : 0.f;
+          s[r] = e;
+        }
       }
       SecondB<T> pb;
       pb.prep(s);
@@ -174,13 +254,28 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s1 = TR::mfma32(kf[1][kk], qf[kk], s1);
     SecondB<T> pb0, pb1;
+    // ONL: this tile's 64 keys are tested together, behind the barrier (which ends a scheduling region anyway, so the phases keep
+    // their interleave): block 0 is exponentiated against the reference the tile started with, and where the test moves the
+    // reference (rare) its S chain is simply run again -- the K fragments are still in registers -- and P~0 recomputed.
+    float bm = -INFINITY;
+    if constexpr (ONL) {
+      if constexpr (MASKED) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float e = fast_exp2(s0[r]);
-      if constexpr (MASKED) e = ((w[0] >> crow(r, 0)) & 1u) ? e : 0.f;
-      s0[r] = e;
+        for (int r = 0; r < 16; ++r) s0[r] = ((w[0] >> crow(r, 0)) & 1u) ? s0[r] : -INFINITY;
+      }
+      bm = max16(s0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[r] = fast_exp2(s0[r]);
+      pb0.prep(s0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = fast_exp2(s0[r]);
+        if constexpr (MASKED) e = ((w[0] >> crow(r, 0)) & 1u) ? e : 0.f;
+        s0[r] = e;
+      }
+      pb0.prep(s0);
     }
-    pb0.prep(s0);
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) { vf1[db][0] = fa.tr_frag(vt, 32, db); vf1[db][1] = fa.tr_frag(vt, 48, db); }
 #pragma unroll
@@ -191,8 +286,32 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     }
     __builtin_amdgcn_sched_barrier(0);
     FCSA_STAMP(ts, 4);
+    if constexpr (ONL) {
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[r] = ((w[1] >> crow(r, 0)) & 1u) ? s1[r] : -INFINITY;
+      }
+      bm = fmaxf(bm, max16(s1));
+    }
     mid();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ONL) {
+      online_recentre<T, G::DB>(bm, c2row, rmax, o, l, lacc, [&](float d) {
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = -c2row;          // (already the new reference)
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) t = TR::mfma32(kf[0][kk], qf[kk], t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if constexpr (MASKED) t[r] = ((w[0] >> crow(r, 0)) & 1u) ? t[r] : -INFINITY;
+          t[r] = fast_exp2(t[r]);
+          s1[r] -= d;
+        }
+        pb0.prep(t);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // --- K fragment requests of the NEXT tile, scheduled among the PV products of block 0 instead of as a burst right behind
     // the barrier (all eight waves bursting 8 ds_read_b128 there took 350 .. 770 ticks of a 2100-tick tile, phase trace; -1.5 %).
     // Branch-free: past the last tile the reads hit the idle buffer and are never used.  (A fully slot-fenced form of this
@@ -215,7 +334,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float e = fast_exp2(s1[r]);
-      if constexpr (MASKED) e = ((w[1] >> crow(r, 0)) & 1u) ? e : 0.f;
+      if constexpr (MASKED && !ONL) e = ((w[1] >> crow(r, 0)) & 1u) ? e : 0.f;      // (ONL: masked exponents are -inf already)
       s1[r] = e;
     }
     pb1.prep(s1);
@@ -238,8 +357,13 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     }
     FCSA_STAMP(ts, 9);
   } else {
-    // generic order (f32, bias): both S chains first, then per block: softmax, PV
+    // generic order (f32, bias, online exponent reference): both S chains first, then per block: softmax, PV
     f32x16 s[2];
+    auto shift_block1 = [&](float d) {        // block 1's logits were accumulated against the reference block 0 has just moved
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[1][r] -= d;
+    };
+    auto nothing = [](float) {};
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
@@ -258,14 +382,16 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
           vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db);
         }
         __builtin_amdgcn_sched_barrier(0);
-        fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
+        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1);
+        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing);
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) {
           o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
           o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
         }
       } else {
-        fwd_softmax_block<T, MASKED, BIAS>(s[jb], pb, l, lacc, p, w[jb], j0 + 32 * jb + 4 * fa.hi, bias_row);
+        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1);
+        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing);
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
       }
@@ -355,8 +481,8 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
   return (!DYN && Traits<T>::ES == 2 && (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0) ? kFwdSub : 1;
 }
 
-// DYN: per-row exponent shift.  A first loop over the K tiles computes every row's max logit (S chains and masks only),
-// the main loop then starts the S accumulators from -max instead of the static shift; inv_l is saved for shift 0.
+// DYN: per-row exponent reference for logit ranges no constant shift can hold, kept online (online_recentre); the S accumulators
+// start from -reference instead of the static shift and inv_l is saved as log2(1 / sum_j exp(S_ij)), i.e. for shift 0.
 template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN>
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
   typedef TileGeom<D, Traits<T>::ES> G;
@@ -425,7 +551,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   // the barrier of tile t.  The FIRST tile is issued here, ahead of the Q fragments and their fused l2norm, so that its
   // HBM / L2 latency hides under that work (the previous pass ended with a barrier: the buffers are free).
   constexpr bool DMA = TR::ES == 2 && (BN * G::ROWB) % 1024 == 0;
-  constexpr bool EARLY = DMA && !DYN;             // (the dynamic-shift pre-pass stages through the same buffers first)
+  constexpr bool EARLY = DMA;
   Stager<T, D, BN, NT> sk, sv;
   typedef DmaStager<T, D, DMA ? BN * SUB : 1024, NW> DS;
   DS dk_, dv_;
@@ -470,60 +596,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   if constexpr (BIAS)
     bias_row = p.bias + ((int64_t)(p.bias_batch ? b : h) * p.N + min(i, p.N - 1)) * (int64_t)p.M * (int64_t)sizeof(typename TR::elem);
 
-  float c2row = p.c2;
-  if constexpr (DYN) {
-    // first pass over the K tiles: row max of the logits (S chains and masks only).  16-bit types: K tiles by LDS-DMA, double
-    // buffered, one barrier per tile (tile t+1 in flight while tile t is reduced); f32: through registers, two barriers per tile.
-    float m2 = -INFINITY;
-    Stager<T, D, BN, NT> s1;
-    if constexpr (!DMA) s1.init(p.k.sn, tid);
-    if constexpr (DMA) {
-      if (nt > 0) dk_.issue(kbase, p.k.sn, Mk, smem, wave);
-    }
-    for (int t = 0; t < nt; ++t) {
-      const int j0 = t * BN;
-      const char* kt = smem;
-      if constexpr (DMA) {
-        kt = smem + (t & 1) * TILE_B;
-        dma_wait();
-        __syncthreads();                     // tile t landed for everyone; every reader of tile t-1 is done
-        if (t + 1 < nt) dk_.issue(kbase + (int64_t)(j0 + BN) * p.k.sn, p.k.sn, Mk - (j0 + BN), smem + ((t + 1) & 1) * TILE_B, wave);
-      } else {
-        s1.load(kbase + (int64_t)j0 * p.k.sn, p.k.sn, Mk - j0);
-        __syncthreads();                     // readers of the previous tile are done
-        s1.store(smem, tid);
-        __syncthreads();
-      }
-      const int key = min(j0 + lane, Mk - 1);
-      const uint64_t word = __ballot((j0 + lane) < Mk && (mrow == nullptr || mrow[key] != 0));
-      if (p.causal && j0 > mw + 31 + diff) continue;       // wave-uniform; the barriers above are still executed
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        const uint32_t w = ((uint32_t)(word >> (32 * jb)) >> (4 * fa.hi)) & (le_mask(i + diff - (j0 + 32 * jb + 4 * fa.hi)) | ncm);
-        u32x4 kfr[G::KS];
-#pragma unroll
-        for (int kk = 0; kk < G::KS; ++kk) kfr[kk] = fa.row_frag(kt, 32 * jb, kk);      // all requests first, then the chain
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(kfr[kk], qf[kk], s);
-        float bv[16];
-        if constexpr (BIAS)      // same wide loads as the main loop (float16 problems with a bias always come through here)
-          load_bias_block<T>(bv, bias_row, j0 + 32 * jb + 4 * fa.hi, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0,
-                             p.bias_c, (p.M & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, fa.hi);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = s[r];
-          if constexpr (BIAS) x += bv[r];
-          m2 = ((w >> crow(r, 0)) & 1u) ? fmaxf(m2, x) : m2;
-        }
-      }
-    }
-    m2 = fmaxf(m2, __shfl_xor(m2, 32, 64));
-    c2row = m2 == -INFINITY ? 0.f : m2;     // rows without a valid key: any finite shift (their P~ are all masked to 0)
-    __syncthreads();
-  }
+  // exponent reference of this lane's row: the problem's constant shift, or (DYN) a per-row value kept online by fwd_softmax_block
+  float c2row = DYN ? 0.f : p.c2;
+  float rmax = -INFINITY;     // DYN: largest exponent seen so far relative to c2row (-inf: no valid key yet)
 
   // Pipeline (per 64-key tile t; two LDS buffers, one register staging set, ONE barrier per tile):
   //   top of t : staging registers (tile t+1, loaded during t-1) -> LDS buffer (t+1)&1; global loads of tile t+2
@@ -644,7 +719,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
       } else {
-        fwd_tile<T, D, MASKED, BIAS, LEAN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
+        fwd_tile<T, D, MASKED, BIAS, LEAN, DYN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
                                      vcur - SUB * TILE_B);
       }
       FCSA_STAMP(ts, 10);
@@ -668,7 +743,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
     continue;
   }
   const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift
-  // saved for the backward in the GLOBAL shift convention; DYN: log2(1 / sum_j exp(S_ij)) = log2(inv) - (row max), which is what
+  // saved for the backward in the GLOBAL shift convention; DYN: log2(1 / sum_j exp(S_ij)) = log2(inv) - (row reference), which is what
   // the backward kernels seed their S accumulators with -- the normaliser itself may not fit f32 at such logit ranges
   if (i < p.N && p.inv_l != nullptr && fa.hi == 0)
     p.inv_l[((int64_t)b * p.H + h) * p.N + i] = DYN ? __builtin_amdgcn_logf(inv) - c2row : inv;
@@ -1107,7 +1182,14 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
-  if (p.dyn) return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);      // dynamic-shift path: one (4-wave) form
+  if (p.dyn) {                  // per-row exponent reference (online): the prefetching form, 8 waves where they fit two per SIMD
+    if constexpr (D * Traits<T>::ES <= 128) {
+      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
+    } else if constexpr (fwd_lean<T, D, BIAS>()) {
+      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true, true>(p, s);
+    }
+    return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);
+  }
   if (p.splits > 1) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);   // split-key path: 128-row tiles x key ranges
   if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);

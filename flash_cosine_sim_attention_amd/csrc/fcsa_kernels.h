@@ -24,7 +24,7 @@ struct FwdParams {
   float bias_c;             // log2(e)              (bias enters as bias * log2e)
   float l_eps;              // clamp of the row sum: 1e-10 (cu:83) rescaled by exp(scale - shift)
   int q_scaled;             // 1: q already carries the factor c1 (fused l2norm writes c1 * q^); 0: the kernel applies it
-  int dyn;                  // 1: per-row exponent shift (row max found by a first pass over K); c2 is 0 then
+  int dyn;                  // 1: per-row exponent reference, kept online by the kernel (online_recentre); c2 is 0 then
   int q_raw;                // 1 (16-bit types, fusable groups): q is the RAW query; the kernel prologue does its grouped l2norm,
                             //    folds c1 in, and publishes the saved state of the backward:
   char* qn_out;             //    [B,H,N,D] contiguous c1 * q^ (dtype), or nullptr when no backward follows

@@ -86,7 +86,8 @@ typedef struct fcsa_problem {
   float   scale;            /* logits = scale * qh.kh ; reference exponent shift = -scale (cu:1216).
                                With l2norm_qk the logit range is +-|scale|*groups.  Where no constant shift fits that
                                range into the exponent of the type P is rounded to (float16: |scale|*groups > 11, or any
-                               attn_bias -- a bias is unbounded and float16 has no room for it; else > 75) the forward kernel shifts every row by its own max logit, normalises it exactly (no
+                               attn_bias -- a bias is unbounded and float16 has no room for it; else > 75) the forward
+                               kernel keeps a per-row exponent reference (online max), normalises the row exactly (no
                                1e-10 clamp: in exp(S - scale) units that clamp would attenuate or zero rows there; the
                                reference kernel itself overflows / zeroes) and saves log2 of the normaliser instead of
                                the normaliser, so any finite scale the public signature admits runs

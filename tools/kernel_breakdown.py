@@ -17,10 +17,14 @@ SHAPES = {
     "d96":   dict(q=(4, 8, 4096, 96), kv=(4, 8, 4096, 96), dtype=torch.bfloat16, causal=True, groups=1),
     "d64f32": dict(q=(2, 8, 2048, 64), kv=(2, 8, 2048, 64), dtype=torch.float32, causal=True, groups=1),
     "C2bias": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype=torch.float16, causal=False, groups=1, bias=True),
+    # per-row exponent reference (online) regimes: f16 beyond scale * groups = 11, bf16 beyond 75
+    "f16s16": dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype=torch.float16, causal=True, groups=1, scale=16),
+    "f16s16d128": dict(q=(4, 8, 4096, 128), kv=(4, 8, 4096, 128), dtype=torch.float16, causal=True, groups=1, scale=16),
+    "C5s16": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype=torch.bfloat16, causal=True, groups=8, scale=16),
     "T5bias": dict(q=(8, 12, 512, 64), kv=(8, 12, 512, 64), dtype=torch.bfloat16, causal=False, groups=1, bias=True),
 }
 sel = sys.argv[1:] or list(SHAPES)
-for name in sel:
+def run_shape(name):
     c = SHAPES[name]
     q = torch.randn(c["q"], device="cuda", dtype=c["dtype"]).requires_grad_()
     k = torch.randn(c["kv"], device="cuda", dtype=c["dtype"]).requires_grad_()
@@ -46,3 +50,10 @@ for name in sel:
         us = s["total_ms"] / s["calls"] * 1e3
         mult = {"fwd": 4, "bwd_dq": 2, "bwd_dkv": 8}.get(s["name"], 0)
         print(f"   {s['name']:<20} calls/step {s['calls']/10:.0f}  avg {us:8.1f} us" + (f"   {mult*unit/us/1e6:7.1f} TF" if mult else ""))
+
+
+for name in sel:
+    try:
+        run_shape(name)
+    except Exception as e:      # e.g. an older library (FCSA_LIB) that refuses the configuration
+        print(name, "failed:", str(e)[:200])
