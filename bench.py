@@ -73,6 +73,8 @@ EXTRA_CONFIGS = {
     "C5": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype="bf16", causal=True, mask=False, scale=1, groups=8, bwd=True),
     "C5s8": dict(q=(4, 8, 2048, 128), kv=(4, 2048, 128), dtype="bf16", causal=True, mask=False, scale=8, groups=8, bwd=True),
     "C3_d128": dict(q=(4, 8, 4096, 128), kv=(4, 8, 4096, 128), dtype="bf16", causal=True, mask=False, scale=8, groups=1, bwd=True),
+    # float16 at scale 16: beyond the constant exponent window (scale * groups > 11), i.e. the forward's online per-row reference
+    "C3_f16_scale16": dict(q=(4, 8, 4096, 64), kv=(4, 8, 4096, 64), dtype="f16", causal=True, mask=False, scale=16, groups=1, bwd=True),
     "C2_bias": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype="f16", causal=False, mask=False, scale=8, groups=1, bwd=True, bias=True),
 }
 _DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
