@@ -971,7 +971,15 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
   // (batch, head) is fixed for the workgroup: everything that does not depend on the pass is set up once
-  const int QT = (p.N + BMQ - 1) / BMQ;
+  // split-query launches (gridDim.y = p.dkv_splits > 1; never causal): this workgroup sees the query tiles [t_lo, QT) of its key tile
+  // only and writes its partial dK^ / dV (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
+  // For key grids that cannot fill the chip: few keys, many queries (the mirror image of the split-key forward / dQ).
+  int QT = (p.N + BMQ - 1) / BMQ, t_lo = 0;
+  if (p.dkv_splits > 1) {
+    const int tps = (QT + p.dkv_splits - 1) / p.dkv_splits;      // query tiles per split
+    t_lo = (int)blockIdx.y * tps;
+    QT = min(QT, t_lo + tps);
+  }
   const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
   const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
   const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
@@ -1027,7 +1035,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   auto geometry = [&](int pass_, int& n0_, int& t0_) {
     const int kt_ = p.causal ? (pass_ == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
     n0_ = kt_ * BNK;
-    t0_ = p.causal ? max(0, n0_ - diff) / BMQ : 0;
+    t0_ = p.causal ? max(0, n0_ - diff) / BMQ : t_lo;
   };
   // requests of a pass that need nothing but a free staging buffer 0: first Q / dO tile (DMA form) with its per-query terms, this
   // lane's K / V fragments, its key-mask byte and the inverse norms its epilogue will use
@@ -1239,8 +1247,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       }
     }
     if (rows_valid > 0) {
-      char* dk0 = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)nw * p.dk.sn;
-      char* dv0 = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)nw * p.dv.sn;
+      const int64_t split_off = p.dkv_splits > 1 ? (int64_t)blockIdx.y * p.dkv_split_stride : 0;
+      char* dk0 = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)nw * p.dk.sn + split_off;
+      char* dv0 = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)nw * p.dv.sn + split_off;
       const char* x0 = fused ? p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)nw * p.k.sn : nullptr;
       EP::template finish<LDS::X>(scr, xs, LDS::XPITCH, le, dk0, p.dk.sn, rows_valid, fused ? false : p.dk_f32 != 0, x0, p.k.sn, 1.f, rinv, p.lgm,
                                   p.norm_eps);
@@ -1352,12 +1361,13 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT), (unsigned)(p.dkv_splits > 1 ? p.dkv_splits : 1)), dim3(NW * 64), lds, s, p);
   return hipGetLastError();
 }
 
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
+  if (p.dkv_splits > 1) return launch_dkv_nw<T, D, BIAS, 4>(p, s);       // split-query path: 128-key tiles x query ranges
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
   } else if constexpr (Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES <= 256) {

@@ -141,6 +141,7 @@ struct BwdLayout {
   size_t delta, dq_slab, dk_slab, dv_slab, total;
   bool need_dq_slab, need_dk_slab, need_dv_slab, fuse_norm;
   int dq_splits;          // > 1: split-key dQ kernel, dq_slab holds dq_splits partial slabs
+  int dkv_splits;         // > 1: split-query dK/dV kernel, dk_slab / dv_slab hold dkv_splits partial slabs each
 };
 
 // Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
@@ -157,6 +158,20 @@ int backward_dq_splits(const fcsa_problem& p) {
   int64_t s = (target + wgs - 1) / wgs;
   if (s > 16) s = 16;
   if (s > p.k_len / 512) s = p.k_len / 512;
+  return s >= 2 ? (int)s : 1;
+}
+
+// Split-query dK/dV: the mirror image -- few keys, many queries (B * H * ceil(M / 128) key tiles cannot fill the chip), not causal,
+// K/V with heads (the single-headed form already reduces over slabs), every split keeps >= 512 queries.  Partial dK^ / dV go to f32
+// slabs [batch * heads][split][M][D] and the finalize kernel sums them (and applies the l2norm backward to dK^).
+int backward_dkv_splits(const fcsa_problem& p) {
+  if (p.causal || p.kv_heads != p.heads) return 1;
+  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.k_len + 127) / 128);
+  const int target = split_target(p);
+  if (wgs <= 0 || wgs >= target / 2) return 1;
+  int64_t s = (target + wgs - 1) / wgs;
+  if (s > 16) s = 16;
+  if (s > p.q_len / 512) s = p.q_len / 512;
   return s >= 2 ? (int)s : 1;
 }
 
@@ -180,13 +195,14 @@ BwdLayout bwd_layout(const fcsa_problem& p) {
   L.fuse_norm = p.l2norm_qk != 0 && fusable_groups(p);
   L.dq_splits = backward_dq_splits(p);
   L.need_dq_slab = (p.l2norm_qk != 0 && !L.fuse_norm) || L.dq_splits > 1;
-  L.need_dk_slab = single || (p.l2norm_qk != 0 && !L.fuse_norm);
-  L.need_dv_slab = single;
+  L.dkv_splits = backward_dkv_splits(p);
+  L.need_dk_slab = single || (p.l2norm_qk != 0 && !L.fuse_norm) || L.dkv_splits > 1;
+  L.need_dv_slab = single || L.dkv_splits > 1;
   size_t off = 0;
   L.delta = off;   off = align_up(off + qn * 4, 256);
   L.dq_slab = off; off = align_up(off + (L.need_dq_slab ? qn * p.dim_head * 4 * (size_t)L.dq_splits : 0), 256);
-  L.dk_slab = off; off = align_up(off + (L.need_dk_slab ? kn * p.dim_head * 4 : 0), 256);
-  L.dv_slab = off; off = align_up(off + (L.need_dv_slab ? kn * p.dim_head * 4 : 0), 256);
+  L.dk_slab = off; off = align_up(off + (L.need_dk_slab ? kn * p.dim_head * 4 * (size_t)L.dkv_splits : 0), 256);
+  L.dv_slab = off; off = align_up(off + (L.need_dv_slab ? kn * p.dim_head * 4 * (size_t)L.dkv_splits : 0), 256);
   L.total = off;
   return L;
 }
@@ -444,9 +460,16 @@ int fcsa_backward(const fcsa_backward_args* a) {
   const bool dq_slab = dq_splits > 1 || (p.l2norm_qk != 0 && !L.fuse_norm);
   bp.dq_splits = dq_splits;
   bp.dq_split_stride = (int64_t)p.q_len * p.dim_head * 4;
+  // split-query dK/dV: same condition on dk / dv (flat (batch, head) index for the finalize kernel); the bias form keeps the unsplit kernel
+  const bool dkv_flat = a->dk.stride0 == (int64_t)p.heads * a->dk.stride1 && a->dv.stride0 == (int64_t)p.heads * a->dv.stride1;
+  const int dkv_splits = (L.dkv_splits > 1 && dkv_flat && a->attn_bias == nullptr) ? L.dkv_splits : 1;
+  const bool dk_slab = dkv_splits > 1 || single || (p.l2norm_qk != 0 && !L.fuse_norm);
+  const bool dv_slab = dkv_splits > 1 || single;
+  bp.dkv_splits = dkv_splits;
+  bp.dkv_split_stride = (int64_t)p.k_len * p.dim_head * 4;
   bp.dq_f32 = dq_slab;
-  bp.dk_f32 = L.need_dk_slab;
-  bp.dv_f32 = L.need_dv_slab;
+  bp.dk_f32 = dk_slab;
+  bp.dv_f32 = dv_slab;
   if (dq_splits > 1) {          // slab layout [batch * heads][split][N][D]: (b, h) block stride = splits * N * D floats
     bp.dq.p = ws + L.dq_slab;
     bp.dq.sn = (int64_t)p.dim_head * 4;
@@ -455,8 +478,17 @@ int fcsa_backward(const fcsa_backward_args* a) {
   } else {
     bp.dq = dq_slab ? contiguous_view(ws + L.dq_slab, p.heads, p.q_len, p.dim_head, 4) : view(a->dq, es);
   }
-  bp.dk = L.need_dk_slab ? contiguous_view(ws + L.dk_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dk, es);
-  bp.dv = L.need_dv_slab ? contiguous_view(ws + L.dv_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dv, es);
+  if (dkv_splits > 1) {         // slab layout [batch * heads][split][M][D], like the split dq slabs
+    bp.dk.p = ws + L.dk_slab;
+    bp.dk.sn = (int64_t)p.dim_head * 4;
+    bp.dk.sh = (int64_t)dkv_splits * p.k_len * p.dim_head * 4;
+    bp.dk.sb = (int64_t)p.heads * bp.dk.sh;
+    bp.dv = bp.dk;
+    bp.dv.p = ws + L.dv_slab;
+  } else {
+    bp.dk = dk_slab ? contiguous_view(ws + L.dk_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dk, es);
+    bp.dv = dv_slab ? contiguous_view(ws + L.dv_slab, p.heads, p.k_len, p.dim_head, 4) : view(a->dv, es);
+  }
   bp.inv_l = a->inv_l;
   bp.delta = reinterpret_cast<float*>(ws + L.delta);
   bp.mask = a->mask;
@@ -472,7 +504,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.q_scaled = p.l2norm_qk ? 1 : 0;
   bp.G = p.groups; bp.lgm = L.fuse_norm ? log2_blocks_per_group(p) : 0; bp.norm_eps = 1e-12f;
   bp.rq = (L.fuse_norm && dq_splits <= 1) ? a->norm.rq : nullptr;    // fused: dq kernel writes the final dq
-  bp.rk = (L.fuse_norm && !single) ? a->norm.rk : nullptr;          // fused: dkv kernel writes the final dk
+  bp.rk = (L.fuse_norm && !single && dkv_splits <= 1) ? a->norm.rk : nullptr;          // fused: dkv kernel writes the final dk
 
   // 1. dQ (also publishes delta), 2. dK/dV, 3. head reduction + l2norm backward where needed
   if (int rc = timed("bwd_dq", "backward dq", s, [&] { return fcsa::launch_backward_dq(p.dtype, p.dim_head, bp, s); })) return rc;
@@ -504,23 +536,30 @@ int fcsa_backward(const fcsa_backward_args* a) {
     if (int rc = timed("finalize", "finalize dq", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
   }
   fcsa::NormBwdParams nk = nb, nv = nb;
-  if (L.need_dk_slab) {
+  if (dk_slab) {
     nk.slab = ws + L.dk_slab; nk.slab_f32 = 1; nk.HS = p.heads; nk.HO = p.kv_heads; nk.L = p.k_len;
     nk.xn_scale = 1.f;
     if (p.l2norm_qk) { nk.xn = static_cast<const char*>(a->norm.kn); nk.inv_norm = a->norm.rk; nk.G = p.groups; }
     else             { nk.xn = nullptr; nk.inv_norm = nullptr; nk.G = 1; }
     nk.dx = view(a->dk, es);
   }
-  if (L.need_dv_slab) {
+  if (dv_slab) {
     nv.slab = ws + L.dv_slab; nv.slab_f32 = 1; nv.HS = p.heads; nv.HO = p.kv_heads; nv.L = p.k_len;
     nv.xn = nullptr; nv.inv_norm = nullptr; nv.G = 1; nv.xn_scale = 1.f;
     nv.dx = view(a->dv, es);
   }
-  if (L.need_dk_slab && L.need_dv_slab) {      // single-headed K/V: both head reductions in one launch
+  if (dkv_splits > 1) {         // the splits are the "heads" of a flat (batch * head) batch, summed down to one
+    for (fcsa::NormBwdParams* n : {&nk, &nv}) {
+      n->B = p.batch * p.heads; n->HS = dkv_splits; n->HO = 1;
+      n->dx.sb = n->dx.sh;        // flat (batch * head) index: stride0 == heads * stride1 (checked above)
+      n->dx.sh = 0;
+    }
+  }
+  if (dk_slab && dv_slab) {      // single-headed K/V, split-query dK/dV: both reductions in one launch
     if (int rc = timed("finalize", "finalize dk+dv", s, [&] { return fcsa::launch_l2norm_bwd_pair(p.dtype, nk, nv, s); })) return rc;
-  } else if (L.need_dk_slab) {
+  } else if (dk_slab) {
     if (int rc = timed("finalize", "finalize dk", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nk, s); })) return rc;
-  } else if (L.need_dv_slab) {
+  } else if (dv_slab) {
     if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nv, s); })) return rc;
   }
   return FCSA_OK;

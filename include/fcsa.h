@@ -142,7 +142,11 @@ typedef struct fcsa_backward_args {
                                     tiles of a bias slice, sums the broadcast index (batch or heads) in float32 registers
                                     and rounds once (reference: f32 atomicAdd per element into a zeroed f32 tensor,
                                     cu:1574-1576, then a cast pass, cu:1912).  No zero-fill, no cast needed. */
-  void*           workspace;     /* >= fcsa_backward_workspace_bytes(&p) bytes, 256-byte aligned */
+  void*           workspace;     /* >= fcsa_backward_workspace_bytes(&p) bytes, 256-byte aligned: delta [B,H,N] f32, plus f32
+                                    slabs where an epilogue cannot finish the job -- partial dq of the split-key dQ kernel, partial
+                                    dk / dv of the split-query dK/dV kernel and of single-headed K/V, l2norm groups that are not
+                                    8 * 2^k features wide.  The split forms also need dq (dk, dv) with stride0 == heads * stride1;
+                                    other layouts run the unsplit kernels. */
   size_t          workspace_bytes;
   void*           stream;
 } fcsa_backward_args;

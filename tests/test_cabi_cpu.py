@@ -139,6 +139,27 @@ def test_backward_workspace_single_head_non_causal_stays_small(lib):
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 1024 * 4) + al(8 * 8 * 1024 * 64 * 4)
 
 
+def test_backward_workspace_split_query_dkv(lib):
+    """Split-query dK/dV (few keys, many queries, not causal, K/V with heads): dkv_splits f32 slabs for dk and for dv, sized by the
+    rule the launch uses (fcsa_capi.hip backward_dkv_splits): batch * heads * ceil(M / 128) key tiles against 512 / 256 workgroups."""
+    al = lambda x: (x + 255) // 256 * 256
+    # 1 x 8 heads x 1024 keys = 64 key tiles -> 8 splits of 1024 queries (its 512 dQ row tiles need no split)
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)
+    slab = 8 * 8 * 1024 * 64 * 4                                # splits x heads x M x D floats
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 8192 * 4) + al(slab) + al(slab)
+    # causal, single-headed K/V and key grids that fill the chip keep the unsplit kernel
+    for kw in (dict(causal=1), dict(kv_heads=1)):
+        q = _problem(**dict(dict(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1), **kw))
+        single = 8 * 1024 * 64 * 4 if kw.get("kv_heads") == 1 else 0
+        assert lib.fcsa_backward_workspace_bytes(C.byref(q)) == al(8 * 8192 * 4) + 2 * al(single)
+    p = _problem(batch=4, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)      # 256 key tiles
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(4 * 8 * 8192 * 4)
+    # 256-byte rows aim at one workgroup per CU: 2 heads x 4 key tiles = 8 -> 16 splits capped by 4096 / 512 = 8
+    p = _problem(batch=1, heads=2, kv_heads=2, q_len=4096, k_len=512, dim_head=128, dtype=2, l2norm_qk=1)
+    slab = 8 * 2 * 512 * 128 * 4
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(2 * 4096 * 4) + al(slab) + al(slab)
+
+
 def test_forward_needs_qn(lib):
     """Inference calls of the 16-bit kernels save no normalised q (the reference's need_store_rowsum == false path, cu:1086)."""
     f = lambda need, **kw: lib.fcsa_forward_needs_qn(C.byref(_problem(l2norm_qk=1, **kw)), need)
