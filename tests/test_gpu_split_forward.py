@@ -94,3 +94,56 @@ def test_split_and_unsplit_agree_through_the_c_abi():
     (o0, l0), (o1, l1) = outs
     assert (o0 - o1).abs().max().item() <= 2.0 ** -7 * o0.abs().max().item()      # one output ulp: the summation order differs
     assert ((l0 - l1).abs() / l0.abs()).max().item() <= 1e-5
+
+
+# Split-query dK/dV (fcsa_capi.hip backward_dkv_splits: few keys, many queries, not causal, K/V with heads): the dK/dV kernel runs
+# gridDim.y query ranges that write partial f32 slabs, one finalize launch sums them (and applies the l2norm backward to dK^).
+# Through the public op, i.e. with the workspace the compiled binding sizes from fcsa_backward_workspace_bytes.
+SPLIT_QUERY_CASES = [
+    # dtype, B, H, N,    M,   D,  mask,  l2norm, groups, non-contiguous k / v
+    ("bf16", 1, 2, 3000, 150, 64, False, True, 1, False),      # 5 splits; N is not a multiple of the query tile
+    ("f16", 2, 2, 1100, 100, 64, True, True, 2, False),        # 2 splits, key mask with a masked tail, 2 l2norm groups
+    ("f32", 1, 2, 1536, 80, 32, False, True, 1, False),        # 3 splits, f32 MFMA path
+    ("bf16", 1, 3, 2048, 300, 128, False, True, 8, False),     # 256-byte rows (64-row query tiles), 9 key tiles
+    ("f16", 1, 2, 1024, 96, 96, False, False, 1, False),       # reference contract: q, k already normalised
+    ("bf16", 1, 2, 2048, 128, 64, False, True, 1, True),       # k, v are views of a [B, M, H, D] tensor (dk, dv come back contiguous)
+]
+
+
+@pytest.mark.parametrize("dtype,B,H,N,M,D,use_mask,l2norm,groups,strided", SPLIT_QUERY_CASES)
+def test_split_query_dkv_matches_oracle(dtype, B, H, N, M, D, use_mask, l2norm, groups, strided):
+    import flash_cosine_sim_attention_amd as F
+    from flash_cosine_sim_attention_amd import _lib
+    dt = DT[dtype]
+    scale = 8.0 / groups if l2norm else 0.125
+    al = lambda x: (x + 255) // 256 * 256
+    prob = _lib.problem(dt, (B, H, H, N, M, D), False, False, l2norm, groups, scale)
+    assert _lib.load().fcsa_backward_workspace_bytes(C.byref(prob)) >= al(B * H * N * 4) + 2 * al(2 * B * H * M * D * 4), \
+        "case would not take the split-query path"
+    g = torch.Generator(device="cuda").manual_seed(N + 13 * M)
+    q = torch.randn((B, H, N, D), device="cuda", dtype=dt, generator=g)
+    if strided:
+        k = torch.randn((B, M, H, D), device="cuda", dtype=dt, generator=g).transpose(1, 2)
+        v = torch.randn((B, M, H, D), device="cuda", dtype=dt, generator=g).transpose(1, 2)
+    else:
+        k = torch.randn((B, H, M, D), device="cuda", dtype=dt, generator=g)
+        v = torch.randn((B, H, M, D), device="cuda", dtype=dt, generator=g)
+    if not l2norm:
+        q, k = torch.nn.functional.normalize(q.float(), dim=-1).to(dt), torch.nn.functional.normalize(k.float(), dim=-1).to(dt)
+    mask = None
+    if use_mask:
+        mask = torch.rand((B, M), device="cuda", generator=g) > 0.3
+        mask[:, 0] = True
+        mask[:, M - 20:] = False
+    q.requires_grad_(); k.requires_grad_(); v.requires_grad_()
+    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups, l2norm_qk=l2norm)
+    do = torch.randn(o.shape, device="cuda", dtype=dt, generator=g)
+    o.backward(do)
+    torch.cuda.synchronize()
+    mk = None if mask is None else _npf(mask).astype(bool)
+    kw = dict(mask=mk, scale=scale, groups=groups, l2norm_qk=l2norm)
+    rdq, rdk, rdv, _ = O.attention_backward(_npf(do), _npf(q), _npf(k), _npf(v), **kw)
+    for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
+        assert torch.isfinite(got).all(), name
+        rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
+        assert rel <= GRAD_TOL[dtype], f"{name} rel-L2 {rel:.3e}"
