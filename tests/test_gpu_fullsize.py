@@ -195,3 +195,30 @@ def test_c1_shape_f32_vs_float64_oracle():
     assert rel(npf(o), ro) <= 1e-5
     for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
         assert rel(npf(got), ref) <= 2e-5, (name, rel(npf(got), ref))
+
+
+def test_tensors_beyond_4_gib_address_the_last_head_correctly():
+    """Maximum sizes: q, k, v, o and the gradients of 4.8 GB each (B72 H32 N8192 D128 bf16), so the last (batch, head) slices start
+    beyond 4 GiB from their tensor's base -- every per-slice offset in the library has to be 64-bit.  The first and the last slice
+    are compared with the same op run on contiguous copies of those slices alone (other launch forms, small offsets)."""
+    import flash_cosine_sim_attention_amd as F
+    B, H, N, D = 72, 32, 8192, 128
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~60 GiB of device memory")
+    g = torch.Generator(device="cuda").manual_seed(41)
+    q, k, v, do = (torch.randn((B, H, N, D), device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(4))
+    assert q.numel() * q.element_size() > 4.4 * 2**30
+    q.requires_grad_(); k.requires_grad_(); v.requires_grad_()
+    o = F.flash_cosine_sim_attention(q, k, v, causal=True)
+    o.backward(do)
+    torch.cuda.synchronize()
+    for b, h in ((0, 0), (B - 1, H - 1), (B // 2, 3)):
+        sq, sk, sv = (t.detach()[b:b + 1, h:h + 1].clone().requires_grad_() for t in (q, k, v))
+        so = F.flash_cosine_sim_attention(sq, sk, sv, causal=True)
+        so.backward(do[b:b + 1, h:h + 1].clone())
+        assert torch.isfinite(o[b, h]).all()
+        assert (o[b, h].float() - so[0, 0].float()).abs().max().item() <= 2e-2
+        for name, big, small in (("dq", q.grad, sq.grad), ("dk", k.grad, sk.grad), ("dv", v.grad, sv.grad)):
+            rel = ((big[b, h].float() - small[0, 0].float()).norm() / small[0, 0].float().norm()).item()
+            assert rel <= 1e-2, f"slice ({b}, {h}): {name} differs from the slice-only run by rel-L2 {rel:.3e}"
