@@ -53,6 +53,32 @@ def _configs(n_cases=96, seed=20260926):
     return out
 
 
+def _configs_long(n_cases=24, seed=20260927):
+    """Long-and-thin shapes (few heads, N or M in the thousands, the other one anything): the split-key forward / dQ and the
+    split-query dK/dV are chosen by the normal dispatch, in random combination with masks, single-headed K/V, groups and bias."""
+    seed = int(os.environ.get("FCSA_FUZZ_SEED", seed))
+    rng = np.random.RandomState(seed + 1)
+    out = []
+    for c in range(n_cases):
+        dtype = rng.choice(["bf16", "f16", "f32"], p=[0.45, 0.4, 0.15])
+        D = int(rng.choice([16, 32, 64, 96, 128], p=[0.1, 0.2, 0.4, 0.15, 0.15]))
+        B, H = int(rng.randint(1, 3)), int(rng.randint(1, 4))
+        long_q = rng.rand() < 0.5
+        N = int(rng.randint(1024, 3000)) if long_q else int(rng.choice([1, 7, 64, 130, 300]))
+        M = int(rng.choice([3, 64, 100, 200, 513])) if long_q else int(rng.randint(1024, 4200))
+        mode = rng.choice(["none", "causal", "mask"], p=[0.5, 0.15, 0.35])
+        groups = int(rng.choice([g for g in (1, 2, 4, 8) if D % g == 0]))
+        l2 = rng.rand() < 0.85
+        scale = float(rng.choice([1, 8, 16]))
+        if scale * groups > 80:
+            scale = 8.0
+        out.append(dict(id=f"L{c:02d}", dtype=str(dtype), B=B, H=H, N=N, M=M, D=D, causal=mode == "causal", mask=mode == "mask",
+                        bias=bool(rng.rand() < 0.15) and N * M <= 600000, bias_batch=bool(rng.rand() < 0.5),
+                        single_kv=bool(rng.rand() < 0.2), groups=groups if l2 else 1, l2norm=bool(l2),
+                        scale=scale if l2 else 0.125, seed=int(rng.randint(1 << 30))))
+    return out
+
+
 def _npf(t):
     return t.detach().cpu().double().numpy()
 
@@ -134,7 +160,7 @@ def evaluate(cfg):
             yield f"{pr}: {name} rel-L2", rel, lim
 
 
-@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: c["id"])
+@pytest.mark.parametrize("cfg", _configs() + _configs_long(), ids=lambda c: c["id"])
 def test_random_config_matches_oracle(cfg):
     for what, got, lim in evaluate(cfg):
         assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"
