@@ -115,6 +115,34 @@ FCSA_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // clamped (their logits are masked by the caller).  A group that lies inside the row is ONE 8- / 16-byte load when the rows keep
 // that alignment (m % 4 == 0: jbase is a multiple of 4) -- the element-wise form issued 16 two-byte loads per block and lane and
 // made the bias path three times slower than the plain one.
+// The 16-bit fast path in two halves, so that a kernel can issue the loads of the NEXT tile's blocks a tile ahead (forward: the L2
+// round trip of a bias row chunk is longer than one block's S chain, and a one-wave-per-SIMD kernel has nothing else to cover it):
+// bias_raw_request = the two 16-byte loads (keys blk + 16 * hi .. + 15 of this lane's row), bias_raw_finish = exchange + convert.
+template <typename T> FCSA_DEV void bias_raw_request(u32x4 (&raw)[2], const char* row, int blk, int hi) {
+  const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const typename Traits<T>::elem*>(row) + blk + 16 * hi);
+  raw[0] = src[0];
+  raw[1] = src[1];
+}
+template <typename T> FCSA_DEV void bias_raw_finish(float (&bv)[16], const u32x4 (&raw)[2], float mul) {
+  uint32_t w[4][2];      // [rq][dword]: keys 8 * rq + 4 * hi + (0, 1 | 2, 3)
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const auto sa = __builtin_amdgcn_permlane32_swap(raw[0][d], raw[0][2 + d], false, false);
+    const auto sb = __builtin_amdgcn_permlane32_swap(raw[1][d], raw[1][2 + d], false, false);
+    w[0][d] = sa[0];
+    w[2][d] = sa[1];
+    w[1][d] = sb[0];
+    w[3][d] = sb[1];
+  }
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    bv[4 * rq + 0] = Traits<T>::lo(w[rq][0]) * mul;
+    bv[4 * rq + 1] = Traits<T>::hi(w[rq][0]) * mul;
+    bv[4 * rq + 2] = Traits<T>::lo(w[rq][1]) * mul;
+    bv[4 * rq + 3] = Traits<T>::hi(w[rq][1]) * mul;
+  }
+}
+
 template <typename T> FCSA_DEV void load_bias_block(float (&bv)[16], const char* row, int jbase, int m_lim, bool rows_aligned, float mul,
                                                     bool rows_aligned8 = false, int hi = 0) {
   typedef typename Traits<T>::elem E;
@@ -127,25 +155,9 @@ template <typename T> FCSA_DEV void load_bias_block(float (&bv)[16], const char*
     // 0..31 of the second).
     const int jb = jbase - 4 * hi;
     if (rows_aligned8 && jb + 31 < m_lim) {
-      const u32x4* src = reinterpret_cast<const u32x4*>(r0 + jb + 16 * hi);
-      const u32x4 a = src[0], b = src[1];
-      uint32_t w[4][2];      // [rq][dword]: keys 8 * rq + 4 * hi + (0, 1 | 2, 3)
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const auto sa = __builtin_amdgcn_permlane32_swap(a[d], a[2 + d], false, false);
-        const auto sb = __builtin_amdgcn_permlane32_swap(b[d], b[2 + d], false, false);
-        w[0][d] = sa[0];
-        w[2][d] = sa[1];
-        w[1][d] = sb[0];
-        w[3][d] = sb[1];
-      }
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        bv[4 * rq + 0] = Traits<T>::lo(w[rq][0]) * mul;
-        bv[4 * rq + 1] = Traits<T>::hi(w[rq][0]) * mul;
-        bv[4 * rq + 2] = Traits<T>::lo(w[rq][1]) * mul;
-        bv[4 * rq + 3] = Traits<T>::hi(w[rq][1]) * mul;
-      }
+      u32x4 raw[2];
+      bias_raw_request<T>(raw, row, jb, hi);
+      bias_raw_finish<T>(bv, raw, mul);
       return;
     }
   }

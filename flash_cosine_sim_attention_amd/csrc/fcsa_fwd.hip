@@ -111,10 +111,17 @@ FCSA_DEV void online_recentre(float bm, float& mref, float& rmax, f32x16 (&o)[DB
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
 template <typename T, int DB, bool MASKED, bool BIAS, bool ONL, typename Other>
 FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lacc, const FwdParams& p, uint32_t w,
-                                int jbase, const char* bias_row, float& mref, float& rmax, f32x16 (&o)[DB], Other&& other) {
+                                int jbase, const char* bias_row, float& mref, float& rmax, f32x16 (&o)[DB], Other&& other,
+                                u32x4 (*braw)[2] = nullptr, bool use_raw = false, int next_blk = -1) {
   typedef Traits<T> TR;
   float bv[16];
-  if constexpr (BIAS) {
+  if constexpr (BIAS && TR::ES == 2) {
+    // raw chunks requested a tile ahead by the kernel (wave-uniform choices); the same registers then take the chunks of the
+    // block at this position of the NEXT tile, a tile's worth of work ahead of their use
+    if (use_raw) bias_raw_finish<T>(bv, *braw, p.bias_c);
+    if (next_blk >= 0) bias_raw_request<T>(*braw, bias_row, next_blk, (jbase >> 2) & 1);
+  }
+  if (BIAS && (TR::ES != 2 || !use_raw)) {
     // loads from clamped (always valid) addresses; out-of-range positions are masked below or never stored, so their value is
     // irrelevant.  bias_row already points at a valid row.
     load_bias_block<T>(bv, bias_row, jbase, p.M, (p.M & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0, p.bias_c,
@@ -168,7 +175,8 @@ template <typename T, int D, bool MASKED, bool BIAS, bool LEAN, bool ONL, typena
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, f32x16& lacc, const FwdParams& p, float& c2row, float& rmax, uint64_t word, uint32_t ncm, int i, int j0, int diff,
-                       const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k, const char* kt) {
+                       const char* bias_row, Trace& ts, Mid&& mid, const char* knext, bool more_k, const char* kt,
+                       u32x4 (*braw)[2][2] = nullptr, bool use_raw = false, int next_j0 = -1) {
 
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -382,16 +390,20 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
           vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1);
-        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing);
+        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1,
+                                                                     braw ? &(*braw)[0] : nullptr, use_raw, next_j0);
+        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing,
+                                                           braw ? &(*braw)[1] : nullptr, use_raw, next_j0 < 0 ? -1 : next_j0 + 32);
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) {
           o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
           o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
         }
       } else {
-        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1);
-        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing);
+        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1,
+                                                                     braw ? &(*braw)[0] : nullptr, use_raw, next_j0);
+        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing,
+                                                           braw ? &(*braw)[1] : nullptr, use_raw, next_j0 < 0 ? -1 : next_j0 + 32);
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
       }
@@ -607,6 +619,19 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   //   PV products of tile t
   // Buffer (t+1)&1 held tile t-1, whose last reads every wave completed before the barrier of t-1.
   uint8_t mb = 1;
+  // BIAS, 16-bit: the raw bias chunks of a tile's two blocks are requested one tile ahead (bias_raw_request) where the whole 64-key
+  // tile lies inside 16-byte-aligned bias rows (wave-uniform); other tiles load inside the block as before
+  constexpr bool BIAS_AHEAD = BIAS && TR::ES == 2;
+  u32x4 bnext[2][2];
+  bool bnext_ok = false;
+  const bool bias_rows16 = BIAS_AHEAD && (p.M & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+  auto request_bias = [&](int j0n) {
+    bnext_ok = bias_rows16 && j0n + BN <= p.M;
+    if (bnext_ok) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) bias_raw_request<T>(bnext[jb], bias_row, j0n + 32 * jb, fa.hi);
+    }
+  };
   u32x4 kf[2][G::KS];
   auto request_k = [&](const char* kt) {
 #pragma unroll
@@ -625,6 +650,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       sv.load(vbase, p.v.sn, Mk);
     }
     if (mrow) mb = lane < Mk ? mrow[lane] : (uint8_t)0;
+    if constexpr (BIAS_AHEAD) request_bias(0);
   }
   // Every prologue load (Q fragments, first tile, mask byte) is complete here on the real path; say so on ALL
   // paths.  Otherwise hipcc's waitcnt model keeps the Q loads pending along the no-tile path, the loop-header
@@ -712,15 +738,20 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         }
         FCSA_STAMP(ts, 6);
       };
+      // (BIAS_AHEAD) this tile's raw bias chunks are in bnext if bcur_ok; each block re-requests its registers for the next tile
+      const bool bcur_ok = bnext_ok;
+      const bool bfut_ok = BIAS_AHEAD && t + 1 < nt && bias_rows16 && j0 + 2 * BN <= p.M;
       bool skip = false;
       if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
       if (!LEAN && !PREFETCH_K && !skip) request_k(vcur - SUB * TILE_B);
       if (skip) {
+        bnext_ok = false;                  // (nothing was requested for the next tile; once a wave skips it skips to the end of the pass)
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
       } else {
         fwd_tile<T, D, MASKED, BIAS, LEAN, DYN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
-                                     vcur - SUB * TILE_B);
+                                     vcur - SUB * TILE_B, BIAS_AHEAD ? &bnext : nullptr, bcur_ok, bfut_ok ? j0 + BN : -1);
+        bnext_ok = bfut_ok;
       }
       FCSA_STAMP(ts, 10);
       if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only

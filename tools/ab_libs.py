@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of several builds of libfcsa_hip.so in ONE process (guide rule 24): per-kernel HIP-event times of the
-C3 step (or --shape B,H,N,D,causal[,M]).  usage: ab_libs.py [--rounds R] [--shape ...] tag1 tag2 ...   ('main' = libfcsa_hip.so)"""
+C3 step (or --shape B,H,N,D,causal[,M[,bias]]).  usage: ab_libs.py [--rounds R] [--shape ...] tag1 tag2 ...   ('main' = libfcsa_hip.so)"""
 import os, sys, argparse, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ from flash_cosine_sim_attention_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal[,M]; several shapes separated by ':'")
+ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal[,M[,bias]]; several shapes separated by ':'")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("tags", nargs="+")
 a = ap.parse_args()
@@ -32,13 +32,16 @@ for t in a.tags:
 def run_shape(shape):
     B, H, N, D, causal, *rest = (int(x) for x in shape.split(","))
     M = rest[0] if rest else N                     # optional sixth field: key length
+    with_bias = len(rest) > 1 and rest[1] != 0     # optional seventh field: 1 = learned bias [H, N, M] (and its gradient)
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     q = torch.randn(B, H, N, D, device="cuda", dtype=dt, requires_grad=True)
     k, v = (torch.randn(B, H, M, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(2))
     do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
+    bias = (0.5 * torch.randn(H, N, M, device="cuda")).to(dt).requires_grad_() if with_bias else None
     def step():
         q.grad = k.grad = v.grad = None
-        F.flash_cosine_sim_attention(q, k, v, causal=bool(causal)).backward(do)
+        if bias is not None: bias.grad = None
+        F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=bool(causal)).backward(do)
     res = {t: {} for t in a.tags}
     for r in range(a.rounds + 1):
         for t in a.tags:
@@ -59,12 +62,13 @@ def run_shape(shape):
         _lib._lib = libs[t]
         assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
         q.grad = k.grad = v.grad = None
-        o = F.flash_cosine_sim_attention(q, k, v, causal=bool(causal))
+        if bias is not None: bias.grad = None
+        o = F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=bool(causal))
         o.backward(do)
         outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
     for t in a.tags[1:]:
         print(f"{t} vs {a.tags[0]}: max|diff| o/dq/dk/dv = " + " ".join(f"{(x - y).abs().max().item():.3g}" for x, y in zip(outs[t], outs[a.tags[0]])))
-    names = ["fwd", "bwd_dq", "bwd_dkv", "finalize", "l2norm"]
+    names = ["fwd", "bwd_dq", "bwd_dkv", "bwd_dbias", "finalize", "l2norm"]
     print(f"shape {shape} {a.dtype}; median (min) us over {a.rounds} interleaved rounds")
     for t in a.tags:
         print(f"{t:12s} " + "  ".join(f"{n} {statistics.median(res[t][n]):7.1f} ({min(res[t][n]):7.1f})" for n in names if n in res[t]))
