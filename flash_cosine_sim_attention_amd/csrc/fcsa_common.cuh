@@ -38,6 +38,7 @@ typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16   bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4  __attribute__((ext_vector_type(4)));
 
 #define FCSA_DEV __device__ __forceinline__
 
@@ -104,6 +105,31 @@ template <> struct Traits<F32> {
     return c;
   }
 };
+
+// Key mask as ONE small MFMA per 32-key block instead of a select per logit.  A key mask (and the zero-filled keys past the end of
+// a ragged last tile) is the same for every query: S^T[j][i] += m_j with m_j = 0 (valid) or -inf (masked) is a rank-1 update, i.e.
+// one more k-step of the S chain whose A operand carries m_j in k-slot 0 of key row j and whose B operand carries 1.0 in k-slot 0
+// of every query column (v_mfma_f32_32x32x8_{bf16,f16}: 2 + 2 operand registers; f32: v_mfma_f32_32x32x2_f32).  2^-inf == 0 then
+// removes the key from P~, from the row sum and from the running max without a single VALU instruction per logit -- the
+// per-element form (bit test, compare, select, and a split cvt_pk + v_perm per pair) was 4 extra VALU instructions per logit:
+// 181 instead of 37 per 64-key tile of the forward, 167 instead of 59 in dQ.  Causal masks are not rank-1 and keep the select
+// (they only touch the tiles on the diagonal).  `valid_bits`: wave-uniform validity bits of the block's 32 keys; rows = keys
+// (lane & 31) in the forward and dQ (S^T = K Q^T).
+template <typename T> FCSA_DEV f32x16 key_mask_rank1(f32x16 c, uint32_t valid_bits, int x /* lane & 31 */, int hi /* lane >> 5 */) {
+  const bool first = hi == 0;
+  const bool m = first && ((valid_bits >> x) & 1u) == 0u;
+  if constexpr (Traits<T>::ES == 4) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(m ? -INFINITY : 0.f, first ? 1.f : 0.f, c, 0, 0, 0);
+  } else if constexpr (sizeof(typename Traits<T>::elem) == 2 && __is_same(typename Traits<T>::elem, _Float16)) {
+    const f16x4 a = {m ? (_Float16)(-INFINITY) : (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const f16x4 b = {first ? (_Float16)1.f : (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0);
+  } else {
+    const s16x4 a = {(short)(m ? 0xFF80 : 0), 0, 0, 0};            // bf16 -inf
+    const s16x4 b = {(short)(first ? 0x3F80 : 0), 0, 0, 0};        // bf16 1.0
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+  }
+}
 
 // A value the optimiser must treat as freshly computed here: keeps per-lane address arithmetic of prologues / epilogues from being
 // hoisted out of the pass loop, where it would stay live across the tile loops and push the kernels over their register budget

@@ -109,11 +109,12 @@ FCSA_DEV void online_recentre(float bm, float& mref, float& rmax, f32x16 (&o)[DB
 }
 
 // exp2 / mask / pack of one 32x32 block of logits (in place): s -> P~ (f32), pb = packed operand, l / lacc updated
-template <typename T, int DB, bool MASKED, bool BIAS, bool ONL, typename Other>
+template <typename T, int DB, int MODE, bool BIAS, bool ONL, typename Other>
 FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lacc, const FwdParams& p, uint32_t w,
                                 int jbase, const char* bias_row, float& mref, float& rmax, f32x16 (&o)[DB], Other&& other,
                                 u32x4 (*braw)[2] = nullptr, bool use_raw = false, int next_blk = -1) {
   typedef Traits<T> TR;
+  constexpr bool MASKED = MODE == 1;      // (MODE 2: the key mask is in the logits already, key_mask_rank1)
   float bv[16];
   if constexpr (BIAS && TR::ES == 2) {
     // raw chunks requested a tile ahead by the kernel (wave-uniform choices); the same registers then take the chunks of the
@@ -171,7 +172,9 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
 // next tile's fragments land during the PV products instead of being waited for at the top of the next tile
 // (phase timing of the previous structure: 690 of 2490 cycles per tile were spent there, right after the barrier,
 // with all four waves bursting their K reads at once).
-template <typename T, int D, bool MASKED, bool BIAS, bool LEAN, bool ONL, typename Mid>
+// MODE: 0 = every pair valid, 1 = causal tiles on the diagonal (and their ragged tails): select per logit, 2 = key mask / ragged
+// tail of a non-causal problem: rank-1 MFMA per block (key_mask_rank1)
+template <typename T, int D, int MODE, bool BIAS, bool LEAN, bool ONL, typename Mid>
 FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>::KS], const FragAddr<T, D>& fa,
                        const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&o)[TileGeom<D, Traits<T>::ES>::DB],
                        float& l, f32x16& lacc, const FwdParams& p, float& c2row, float& rmax, uint64_t word, uint32_t ncm, int i, int j0, int diff,
@@ -180,7 +183,9 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
 
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
   constexpr bool PREFETCH_K = !LEAN && D * TR::ES < 512;     // see fwd_kernel
+  const int kx = fa.row_off / G::ROWB;      // lane & 31: the key row this lane holds in an A operand
   // validity bits of this lane's 16 keys per block.  Branch-free and BEFORE the MFMA chains on purpose: a runtime
   // branch between the last MFMA and the first read of its result gets too few wait states on the
   // taken path (hipcc 7.2 pads only the fall-through; seen with the 16-pass v_mfma_f32_32x32x2_f32).
@@ -200,6 +205,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = -c2row;
+      if constexpr (KEYM) s = key_mask_rank1<T>(s, (uint32_t)(word >> (32 * jb)), kx, fa.hi);
       constexpr int PF = 4;
 #pragma unroll
       for (int k0 = 0; k0 < G::KS; k0 += PF) {
@@ -251,6 +257,10 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = -c2row; s1[r] = -c2row; }   // exponent shift (static, or this row's max) as the accumulator's initial value
+    if constexpr (KEYM) {
+      s0 = key_mask_rank1<T>(s0, (uint32_t)word, kx, fa.hi);
+      s1 = key_mask_rank1<T>(s1, (uint32_t)(word >> 32), kx, fa.hi);
+    }
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s0 = TR::mfma32(kf[0][kk], qf[kk], s0);
     u32x4 vf0[G::DB][2], vf1[G::DB][2];
@@ -308,6 +318,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = -c2row;          // (already the new reference)
+        if constexpr (KEYM) t = key_mask_rank1<T>(t, (uint32_t)word, kx, fa.hi);
 #pragma unroll
         for (int kk = 0; kk < G::KS; ++kk) t = TR::mfma32(kf[0][kk], qf[kk], t);
 #pragma unroll
@@ -376,6 +387,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[jb][r] = -c2row;
+      if constexpr (KEYM) s[jb] = key_mask_rank1<T>(s[jb], (uint32_t)(word >> (32 * jb)), kx, fa.hi);
 #pragma unroll
       for (int kk = 0; kk < G::KS; ++kk) s[jb] = TR::mfma32(kf[jb][kk], qf[kk], s[jb]);
     }
@@ -390,9 +402,9 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
           vf[db][1] = fa.tr_frag(vt, 32 * jb + 16, db);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1,
+        if (jb == 0) fwd_softmax_block<T, G::DB, MODE, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1,
                                                                      braw ? &(*braw)[0] : nullptr, use_raw, next_j0);
-        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing,
+        else fwd_softmax_block<T, G::DB, MODE, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing,
                                                            braw ? &(*braw)[1] : nullptr, use_raw, next_j0 < 0 ? -1 : next_j0 + 32);
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) {
@@ -400,9 +412,9 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
           o[db] = TR::mfma32(vf[db][1], pb.v[1], o[db]);
         }
       } else {
-        if (jb == 0) fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1,
+        if (jb == 0) fwd_softmax_block<T, G::DB, MODE, BIAS, ONL>(s[0], pb, l, lacc, p, w[0], j0 + 4 * fa.hi, bias_row, c2row, rmax, o, shift_block1,
                                                                      braw ? &(*braw)[0] : nullptr, use_raw, next_j0);
-        else fwd_softmax_block<T, G::DB, MASKED, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing,
+        else fwd_softmax_block<T, G::DB, MODE, BIAS, ONL>(s[1], pb, l, lacc, p, w[1], j0 + 32 + 4 * fa.hi, bias_row, c2row, rmax, o, nothing,
                                                            braw ? &(*braw)[1] : nullptr, use_raw, next_j0 < 0 ? -1 : next_j0 + 32);
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) o[db] = second_mma<T, D>(o[db], vt, 32 * jb, db, pb, fa);
@@ -495,8 +507,11 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 
 // DYN: per-row exponent reference for logit ranges no constant shift can hold, kept online (online_recentre); the S accumulators
 // start from -reference instead of the static shift and inv_l is saved as log2(1 / sum_j exp(S_ij)), i.e. for shift 0.
-template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN>
+// KM: the launch is NOT causal (compile-time: a third tile loop in one kernel made hipcc spill 200 registers): tiles that need
+// masking -- a key mask, the ragged last tile -- take the rank-1 MFMA form (fwd_tile MODE 2) instead of the per-logit select.
+template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN, bool KM>
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
+  const bool causal = !KM && p.causal;
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
@@ -515,11 +530,11 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   // start to finish on one CU, so the makespan would be set by the heaviest tile.  Each workgroup therefore
   // takes a PAIR of row tiles (MT-1-pt, pt): constant work per workgroup.  Non-causal: one tile each.
   const int MT = (p.N + BM - 1) / BM;
-  const int PT = p.causal ? (MT + 1) / 2 : MT;
+  const int PT = causal ? (MT + 1) / 2 : MT;
   int bh, pt;
   block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
-  const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
+  const int npass = (causal && (MT - 1 - pt) != pt) ? 2 : 1;
   // split-key launches (gridDim.y = p.splits > 1, never causal / bias / dynamic shift): this workgroup sees the keys
   // [k_lo, k_lo + Mk) only and writes un-normalised partials; everything below works on that sub-problem
   int k_lo = 0, Mk = p.M;
@@ -529,7 +544,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
     Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
   }
   const int diff = p.M - p.N - k_lo;              // cu:1097 seq_len_diff (in the sub-problem's key numbering)
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
+  const uint32_t ncm = causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
 #ifdef FCSA_TRACE_WG
@@ -546,14 +561,14 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
 #endif
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
-  const int mt = p.causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
+  const int mt = causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
   const int mw = m0 + wave * 32;                  // first query row of this wave
   const int i = mw + (lane & 31);                 // this lane's query row
 
   // key tiles this workgroup needs
   int last_key = Mk - 1;
-  if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
+  if (causal) last_key = min(last_key, m0 + BM - 1 + diff);
   const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
@@ -678,12 +693,13 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   int t_split = 0;
   if (!BIAS && mrow == nullptr) {
     t_split = Mk / BN;                                                 // tail tile (j0 + BN > Mk) is masked
-    if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);  // needs (t+1)*BN - 1 <= mw + diff
+    if (causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);  // needs (t+1)*BN - 1 <= mw + diff
     t_split = min(t_split, nt);
   }
 
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int MODE = decltype(masked_tag)::value;      // fwd_tile: 0 all valid, 1 causal select, 2 key mask by rank-1 MFMA
+    constexpr bool MASKED = MODE != 0;
     for (int t = t_begin; t < t_end; ++t) {
 #ifdef FCSA_TRACE
       if (t == t_begin + 1) first_iter[pass][MASKED ? 1 : 0] = trace_now() - first_iter[pass][MASKED ? 1 : 0];
@@ -742,14 +758,14 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       const bool bcur_ok = bnext_ok;
       const bool bfut_ok = BIAS_AHEAD && t + 1 < nt && bias_rows16 && j0 + 2 * BN <= p.M;
       bool skip = false;
-      if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
+      if constexpr (MASKED) skip = causal && (j0 > mw + 31 + diff);              // no valid pair for this wave
       if (!LEAN && !PREFETCH_K && !skip) request_k(vcur - SUB * TILE_B);
       if (skip) {
         bnext_ok = false;                  // (nothing was requested for the next tile; once a wave skips it skips to the end of the pass)
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
       } else {
-        fwd_tile<T, D, MASKED, BIAS, LEAN, DYN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
+        fwd_tile<T, D, MODE, BIAS, LEAN, DYN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
                                      vcur - SUB * TILE_B, BIAS_AHEAD ? &bnext : nullptr, bcur_ok, bfut_ok ? j0 + BN : -1);
         bnext_ok = bfut_ok;
       }
@@ -757,8 +773,8 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only
     }
   };
-  run(std::false_type{}, 0, t_split);
-  run(std::true_type{}, t_split, nt);
+  run(std::integral_constant<int, 0>{}, 0, t_split);
+  run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
   FCSA_PASS_MARK(3);
   // no trailing barrier: every wave completed its last LDS read before the final mid() barrier, so the next
   // pass may overwrite buffer 0 in its prologue
@@ -1199,10 +1215,19 @@ static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   size_t lds = 4 * 64 * fwd_stage_tiles<T, D, DYN>() * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K + V tiles of a stage)
   if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES_NOX) lds = (size_t)NW * RowEpilogue<T, D>::BYTES_NOX;   // epilogue scratch reuses the same bytes
-  auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN>;
-  static std::atomic<uint64_t> lds_ok{0};
-  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT), (unsigned)(p.splits > 1 ? p.splits : 1)), dim3(NW * 64), lds, s, p);
+  // two instantiations: causal launches (select per logit on the diagonal tiles) and the others (key masks as a rank-1 MFMA)
+  const dim3 grid((unsigned)(p.B * p.H * PT), (unsigned)(p.splits > 1 ? p.splits : 1));
+  if (p.causal) {
+    auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN, false>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+  } else {
+    auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN, true>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+  }
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (p.splits > 1) {
     const int64_t items = (int64_t)p.B * p.H * p.N * (D / 8);

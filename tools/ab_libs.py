@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of several builds of libfcsa_hip.so in ONE process (guide rule 24): per-kernel HIP-event times of the
-C3 step (or --shape B,H,N,D,causal[,M[,bias]]).  usage: ab_libs.py [--rounds R] [--shape ...] tag1 tag2 ...   ('main' = libfcsa_hip.so)"""
+C3 step (or --shape B,H,N,D,causal[,M[,bias[,mask]]]).  usage: ab_libs.py [--rounds R] [--shape ...] tag1 tag2 ...   ('main' = libfcsa_hip.so)"""
 import os, sys, argparse, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ from flash_cosine_sim_attention_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal[,M[,bias]]; several shapes separated by ':'")
+ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal[,M[,bias[,mask]]]; several shapes separated by ':'")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("tags", nargs="+")
 a = ap.parse_args()
@@ -33,6 +33,8 @@ def run_shape(shape):
     B, H, N, D, causal, *rest = (int(x) for x in shape.split(","))
     M = rest[0] if rest else N                     # optional sixth field: key length
     with_bias = len(rest) > 1 and rest[1] != 0     # optional seventh field: 1 = learned bias [H, N, M] (and its gradient)
+    with_mask = len(rest) > 2 and rest[2] != 0     # optional eighth field: 1 = random key mask, 25 % masked (the README protocol)
+    mask = (torch.rand(B, M, device="cuda") > 0.25) if with_mask else None
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     q = torch.randn(B, H, N, D, device="cuda", dtype=dt, requires_grad=True)
     k, v = (torch.randn(B, H, M, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(2))
@@ -41,7 +43,7 @@ def run_shape(shape):
     def step():
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=bool(causal)).backward(do)
+        F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal)).backward(do)
     res = {t: {} for t in a.tags}
     for r in range(a.rounds + 1):
         for t in a.tags:
@@ -63,7 +65,7 @@ def run_shape(shape):
         assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        o = F.flash_cosine_sim_attention(q, k, v, attn_bias=bias, causal=bool(causal))
+        o = F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal))
         o.backward(do)
         outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
     for t in a.tags[1:]:
