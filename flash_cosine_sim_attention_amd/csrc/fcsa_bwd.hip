@@ -57,13 +57,16 @@ __device__ unsigned long long g_trace_pass_dkv[2560];
 // =============================================================================================
 // dQ kernel
 // =============================================================================================
-template <typename T, int D, bool MASKED, bool BIAS, bool TWO>
+// MODE: 0 = every pair valid, 1 = causal diagonal tiles (select per logit), 2 = key mask / ragged tail of a non-causal launch
+// (rank-1 MFMA per block, key_mask_rank1)
+template <typename T, int D, int MODE, bool BIAS, bool TWO>
 FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
                       const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS],
                       f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB], float lc, float delta, const BwdParams& p, uint64_t word,
                       uint32_t ncm, int i, int j0, int diff, const char* bias_row, int m_lim) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
     // branch-free and before the MFMA chains on purpose (see fwd_tile)
@@ -77,6 +80,7 @@ FCSA_DEV void dq_tile(const char* kt, const char* vt, const FragAddr<T, D>& fa,
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = -delta; }  // lc = log2(inv_l) - c2 and -delta ride in as initial values
+    if constexpr (KEYM) s = key_mask_rank1<T>(s, (uint32_t)(word >> (32 * jb)), fa.row_off / G::ROWB, fa.hi);
 #pragma unroll
     for (int k0 = 0; k0 < G::KS; k0 += PF) {
       u32x4 kfr[PF], vfr[PF];
@@ -130,13 +134,14 @@ template <typename T, int D> struct DqPipe {
   }
 };
 
-template <typename T, int D, bool MASKED>
+template <typename T, int D, int MODE>
 FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, const char* vnext, int next_tile, int t,
                            const FragAddr<T, D>& fa, const u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS],
                            const u32x4 (&dof)[TileGeom<D, Traits<T>::ES>::KS], f32x16 (&dq)[TileGeom<D, Traits<T>::ES>::DB],
                            float lc, float delta, uint64_t word, uint32_t ncm, int i, int j0, int diff, DqPipe<T, D>& pp_) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
   if (pp_.tile != t) pp_.request(kt, vt, fa, 0);        // first tile of a stage (or after skipped tiles): exposed request
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
@@ -148,6 +153,7 @@ FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, co
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = lc; dp[r] = -delta; }     // lc = log2(inv_l) - c2 and -delta ride in as initial values
+    if constexpr (KEYM) s = key_mask_rank1<T>(s, (uint32_t)(word >> (32 * jb)), fa.row_off / G::ROWB, fa.hi);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.kfr[kk], qf[kk], s);
 #pragma unroll
@@ -210,8 +216,10 @@ template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false> stru
 // SUB = 64-key tiles per LDS stage: 1, or 2 / 4 in the 8-wave form (one workgroup per CU has the LDS for 128- / 256-key stages).
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
-template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO>
+// KM: the launch is not causal; tiles that need masking take the rank-1 form (see fwd_kernel)
+template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO, bool KM>
 __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+  const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64, BNS = BN * SUB;
@@ -227,12 +235,12 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
 
   // causal: a workgroup takes the PAIR of row tiles (MT-1-pt, pt) -> constant work per workgroup (see fwd_kernel)
   const int MT = (p.N + BM - 1) / BM;
-  const int PT = p.causal ? (MT + 1) / 2 : MT;
+  const int PT = causal ? (MT + 1) / 2 : MT;
   // (d_bias is not this kernel's business: bwd_dbias_kernel below recomputes the dS tiles of a bias slice and writes it once)
   int bh, pt;
   block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
-  const int npass = (p.causal && (MT - 1 - pt) != pt) ? 2 : 1;
+  const int npass = (causal && (MT - 1 - pt) != pt) ? 2 : 1;
   // split-key launches (gridDim.y = p.dq_splits > 1; never causal): this workgroup sees the keys [k_lo, k_lo + Mk) only and
   // writes its partial dQ^ (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
   // Like the forward's split (fcsa_fwd.hip), for grids whose row tiles cannot fill the chip.
@@ -243,7 +251,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
   }
   const int diff = p.M - p.N - k_lo;
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
+  const uint32_t ncm = causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
 #ifdef FCSA_TRACE_WG
@@ -284,10 +292,10 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   }
   // geometry of iteration (pass_): row tile, this lane's row, number of 64-key tiles
   auto geometry = [&](int pass_, int& m0_, int& nt_) {
-    const int mt_ = p.causal ? (pass_ == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
+    const int mt_ = causal ? (pass_ == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
     m0_ = mt_ * BM;
     int last_key = Mk - 1;
-    if (p.causal) last_key = min(last_key, m0_ + BM - 1 + diff);
+    if (causal) last_key = min(last_key, m0_ + BM - 1 + diff);
     nt_ = last_key < 0 ? 0 : last_key / BN + 1;
   };
   // requests of an iteration that need nothing but free staging buffers: first K / V stage (DMA form) and the raw row chunks
@@ -425,14 +433,15 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   int t_split = 0;                                 // see fwd_kernel
   if (!BIAS && mrow == nullptr) {
     t_split = Mk / BN;
-    if (p.causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);
+    if (causal) t_split = min(t_split, max(0, mw + diff + 1) / BN);
     t_split = min(t_split, nt);
   }
 
   DqPipe<T, D> pipe;
   pipe.tile = -1;
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int MODE = decltype(masked_tag)::value;      // dq_tile: 0 all valid, 1 causal select, 2 key mask by rank-1 MFMA
+    constexpr bool MASKED = MODE != 0;
     for (int t = t_begin; t < t_end; ++t) {
       const int j0 = t * BN;
       const int u = t / SUB, sub = t % SUB;
@@ -469,15 +478,15 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
       FCSA_STAMP(ts, 1);
       if constexpr (TR::ES == 2 && !BIAS && !TWO) {      // pipelined tile: one wave per SIMD only
         bool skip = false;
-        if constexpr (MASKED) skip = p.causal && (j0 > mw + 31 + diff);
+        if constexpr (MASKED) skip = causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
-        if (!skip) dq_tile_pipe<T, D, MASKED>(kcur, vcur, next_here ? kcur + TILE_B : kcur, next_here ? vcur + TILE_B : vcur,
+        if (!skip) dq_tile_pipe<T, D, MODE>(kcur, vcur, next_here ? kcur + TILE_B : kcur, next_here ? vcur + TILE_B : vcur,
                                               next_here ? t + 1 : -1, t, fa, qf, dof, dq, lc, delta, word, ncm, i, j0, diff, pipe);
       } else if constexpr (MASKED) {
-        const bool skip = p.causal && (j0 > mw + 31 + diff);
-        if (!skip) dq_tile<T, D, true, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
+        const bool skip = causal && (j0 > mw + 31 + diff);
+        if (!skip) dq_tile<T, D, MODE, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
       } else {
-        dq_tile<T, D, false, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
+        dq_tile<T, D, 0, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
       }
       FCSA_STAMP(ts, 2);
       if (last_of_stage) {                                 // workgroup-uniform
@@ -497,9 +506,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     }
   };
   FCSA_PASS_MARK(1);
-  run(std::false_type{}, 0, t_split);
+  run(std::integral_constant<int, 0>{}, 0, t_split);
   FCSA_PASS_MARK(2);
-  run(std::true_type{}, t_split, nt);
+  run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
   FCSA_PASS_MARK(3);
 
   // Epilogue through the LDS (RowEpilogue): every stage ended with a barrier, so no wave still reads the staging buffers.
@@ -745,7 +754,9 @@ static hipError_t launch_dbias_t(const BwdParams& p, hipStream_t s) {
 // LEAN: the B operand of the dP chain (this lane's V row) is read from `vown`, the LDS copy of the workgroup's own V rows, next to
 // each MFMA instead of being held in registers (`vf` is unused): with the dk / dv accumulators (128 registers at D = 128) and the K
 // fragments this is what lets the kernel run two waves per SIMD at 16-bit D = 96 / 128.
-template <typename T, int D, int BMQ, bool MASKED, bool BIAS, bool LEAN = false>
+// MODE: 0 / 1 as in dq_tile; 2 = key mask of a non-causal launch: the lanes ARE the keys here (S = Q K^T, columns = keys), so the
+// rank-1 term is ones (A, query rows) x this lane's 0 / -inf (B): `kmb` = the B operand's k-slot-0 register pair, set up once per pass
+template <typename T, int D, int BMQ, int MODE, bool BIAS, bool LEAN = false>
 FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                        const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
@@ -754,6 +765,7 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
                        int vrow0 = 0) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
 #pragma unroll
   for (int ib = 0; ib < BMQ / 32; ++ib) {
     if constexpr (LEAN) FCSA_FENCE();      // blocks stay apart: interleaved by the scheduler, two blocks' fragments do not fit 256 registers
@@ -777,6 +789,7 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s[4 * rq + e] = lc4[e]; dp[4 * rq + e] = nd4[e]; }
     }
+    if constexpr (KEYM) s = key_mask_rank1_cols<T>(s, kmask == 0u, fa.hi);
     // (row fragments are requested next to their MFMA here: this kernel sits at its register budget, and
     //  batching the requests as in dq_tile spills)
 #pragma unroll
@@ -856,13 +869,14 @@ struct DkvPipe {
   }
 };
 
-template <typename T, int D, int BMQ, bool MASKED>
+template <typename T, int D, int BMQ, int MODE>
 FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                             const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                             f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
                             uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
+  constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
   constexpr int NB = BMQ / 32;
   DkvPipe<T, D, BMQ> pp_;
   pp_.request(qt, dot, lcs, dls, fa, 0);
@@ -874,6 +888,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     if (ib == 1) FCSA_STAMP(ts, 2);
     // ---- M1: S = Q K^T + lc, dP = dO V^T - delta (the per-query terms are the accumulators' initial values)
     f32x16 s = pp_.s, dp = pp_.dp;
+    if constexpr (KEYM) s = key_mask_rank1_cols<T>(s, kmask == 0u, fa.hi);
 #pragma unroll
     for (int kk = 0; kk < G::KS; ++kk) s = TR::mfma32(pp_.qa[kk], kf[kk], s);
 #pragma unroll
@@ -931,8 +946,9 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
   }
 }
 
-template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false>
+template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes || LEAN) ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+  const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BNK = 32 * NW, NT = NW * 64;
@@ -951,11 +967,11 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
 
   // causal: the LOW key tiles are the heavy ones (they see every later query); pair (pt, KT-1-pt) per workgroup
   const int KT = (p.M + BNK - 1) / BNK;
-  const int PT = p.causal ? (KT + 1) / 2 : KT;
+  const int PT = causal ? (KT + 1) / 2 : KT;
   int bh, pt;
   block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
-  const int npass = (p.causal && (KT - 1 - pt) != pt) ? 2 : 1;
+  const int npass = (causal && (KT - 1 - pt) != pt) ? 2 : 1;
   const int diff = p.M - p.N;
   Trace ts;
   ts.reset();
@@ -1033,9 +1049,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   };
   // geometry of a pass: first key of the workgroup's key tile, first query tile it needs (causal keeps i >= j - diff)
   auto geometry = [&](int pass_, int& n0_, int& t0_) {
-    const int kt_ = p.causal ? (pass_ == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
+    const int kt_ = causal ? (pass_ == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
     n0_ = kt_ * BNK;
-    t0_ = p.causal ? max(0, n0_ - diff) / BMQ : t_lo;
+    t0_ = causal ? max(0, n0_ - diff) / BMQ : t_lo;
   };
   // requests of a pass that need nothing but a free staging buffer 0: first Q / dO tile (DMA form) with its per-query terms, this
   // lane's K / V fragments, its key-mask byte and the inverse norms its epilogue will use
@@ -1138,7 +1154,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   }
   const bool key_ok = j < p.M && rmask != 0;
   const uint32_t kmask = key_ok ? 0xffffffffu : 0u;      // this lane's key: valid for every query or for none
-  const uint32_t ncm = p.causal ? 0u : 0xffffffffu;
+  const uint32_t ncm = causal ? 0u : 0xffffffffu;
 
   f32x16 dk[G::DB], dv[G::DB];
 #pragma unroll
@@ -1160,11 +1176,12 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   int t_m = QT;
   if (!BIAS && p.mask == nullptr && n0 + BNK <= p.M) {
     t_m = t0;
-    if (p.causal) t_m = min(QT, max(t0, (nw + 31 - diff + BMQ - 1) / BMQ));
+    if (causal) t_m = min(QT, max(t0, (nw + 31 - diff + BMQ - 1) / BMQ));
   }
 
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int MODE = decltype(masked_tag)::value;      // dkv_tile: 0 all valid, 1 causal select, 2 key mask by rank-1 MFMA
+    constexpr bool MASKED = MODE != 0;
     for (int t = t_begin; t < t_end; ++t) {
       const int i0 = t * BMQ;
       const int par = (t - t0) & 1;
@@ -1192,16 +1209,16 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       }
       {
       bool skip = false;
-      if constexpr (MASKED) skip = p.causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
+      if constexpr (MASKED) skip = causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
       if constexpr (PIPE) {
-        if (!skip) dkv_tile_pipe<T, D, BMQ, MASKED>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
+        if (!skip) dkv_tile_pipe<T, D, BMQ, MODE>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
       } else if constexpr (LEAN) {
-        if (!skip) dkv_tile<T, D, BMQ, MASKED, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
+        if (!skip) dkv_tile<T, D, BMQ, MODE, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
                                                             bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32);
       } else {
         const int next_i0 = more ? i0 + BMQ : -1;
         if (!skip) {
-          dkv_tile<T, D, BMQ, MASKED, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
+          dkv_tile<T, D, BMQ, MODE, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
                                             bias_blk, bvec, next_i0, lane);
         } else if constexpr (BIAS) {      // the block requested for this tile is not used: request the next tile's first block instead
           if (bvec && more) bb.request(bias_blk, min(next_i0 + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
@@ -1217,9 +1234,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
     }
   };
   FCSA_PASS_MARK(1);
-  run(std::true_type{}, t0, t_m);
+  run(std::integral_constant<int, KM ? 2 : 1>{}, t0, t_m);
   FCSA_PASS_MARK(2);
-  run(std::false_type{}, t_m, QT);
+  run(std::integral_constant<int, 0>{}, t_m, QT);
   FCSA_PASS_MARK(3);
 
   // Epilogue through the LDS (RowEpilogue): every tile ended with a barrier, so no wave still reads the staging buffers.
@@ -1320,10 +1337,20 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   // 8-wave form: 256-key stages where they arrive by LDS-DMA (no staging registers), 128-key stages through registers (f32)
   constexpr int SUB = NW == 8 ? (Traits<T>::ES == 2 ? kDqSub8 : 2) : 1;
   const size_t lds = DqLds<T, D, NW, SUB, TWO>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
-  auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO>;
-  static std::atomic<uint64_t> lds_ok{0};
-  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.H * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1)), dim3(NW * 64), lds, s, p);
+  const dim3 grid((unsigned)((int64_t)p.B * p.H * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1));
+  // (two instantiations, see launch_fwd_nw.  The two-wave form of 256-byte rows sits at its 256 registers: its non-causal
+  //  instantiation came out with spill reloads inside the tile loops -- +5.6 % time -- so those launches keep the general kernel)
+  if (p.causal || (TWO && D * Traits<T>::ES >= 256)) {
+    auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, false>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+  } else {
+    auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, true>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+  }
   return hipGetLastError();
 }
 
@@ -1358,10 +1385,18 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   const int PT = p.causal ? (KT + 1) / 2 : KT;
   // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
   const size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
-  auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN>;
-  static std::atomic<uint64_t> lds_ok{0};
-  if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT), (unsigned)(p.dkv_splits > 1 ? p.dkv_splits : 1)), dim3(NW * 64), lds, s, p);
+  const dim3 grid((unsigned)(p.B * p.H * PT), (unsigned)(p.dkv_splits > 1 ? p.dkv_splits : 1));
+  if (p.causal) {        // (two instantiations, see launch_fwd_nw)
+    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, false>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+  } else {
+    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, true>;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+  }
   return hipGetLastError();
 }
 

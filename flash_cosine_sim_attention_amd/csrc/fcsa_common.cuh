@@ -120,13 +120,31 @@ template <typename T> FCSA_DEV f32x16 key_mask_rank1(f32x16 c, uint32_t valid_bi
   const bool m = first && ((valid_bits >> x) & 1u) == 0u;
   if constexpr (Traits<T>::ES == 4) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(m ? -INFINITY : 0.f, first ? 1.f : 0.f, c, 0, 0, 0);
-  } else if constexpr (sizeof(typename Traits<T>::elem) == 2 && __is_same(typename Traits<T>::elem, _Float16)) {
+  } else if constexpr (__is_same(typename Traits<T>::elem, _Float16)) {
     const f16x4 a = {m ? (_Float16)(-INFINITY) : (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     const f16x4 b = {first ? (_Float16)1.f : (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0);
   } else {
     const s16x4 a = {(short)(m ? 0xFF80 : 0), 0, 0, 0};            // bf16 -inf
     const s16x4 b = {(short)(first ? 0x3F80 : 0), 0, 0, 0};        // bf16 1.0
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+  }
+}
+
+// The same for kernels whose lanes (C columns) are the keys (dK/dV: S = Q K^T): ones in the A operand's k-slot 0 (every query row),
+// this lane's 0 / -inf in the B operand's.
+template <typename T> FCSA_DEV f32x16 key_mask_rank1_cols(f32x16 c, bool key_masked, int hi /* lane >> 5 */) {
+  const bool first = hi == 0;
+  const bool m = first && key_masked;
+  if constexpr (Traits<T>::ES == 4) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(first ? 1.f : 0.f, m ? -INFINITY : 0.f, c, 0, 0, 0);
+  } else if constexpr (__is_same(typename Traits<T>::elem, _Float16)) {
+    const f16x4 a = {first ? (_Float16)1.f : (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const f16x4 b = {m ? (_Float16)(-INFINITY) : (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0);
+  } else {
+    const s16x4 a = {(short)(first ? 0x3F80 : 0), 0, 0, 0};
+    const s16x4 b = {(short)(m ? 0xFF80 : 0), 0, 0, 0};
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
   }
 }

@@ -511,7 +511,7 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 // masking -- a key mask, the ragged last tile -- take the rank-1 MFMA form (fwd_tile MODE 2) instead of the per-logit select.
 template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN, bool KM>
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
-  const bool causal = !KM && p.causal;
+  const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
