@@ -1259,7 +1259,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
 template <typename T, int D>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
   if constexpr (Traits<T>::ES == 2 && D <= 64) {       // (D = 96 / 128 take the lean two-wave kernel, see use_wide_fwd)
-    if (p.bias == nullptr && !p.dyn && p.splits <= 1 && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
+    if (p.bias == nullptr && !p.dyn && p.splits <= 1 && p.mask == nullptr && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
   }
   return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);
 }
