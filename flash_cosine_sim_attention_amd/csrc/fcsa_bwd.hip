@@ -25,7 +25,10 @@
 // are deterministic, d_bias included (a workgroup owns its slice of d_bias and reduces the broadcast index itself: no atomics,
 // cf. cu:1574-1576).
 // As in the forward kernel, each kernel runs its unmasked tiles and its masked tiles in two
-// sequential loops with one straight-line body each (no accumulator copies at if/else joins).
+// sequential loops with one straight-line body each (no accumulator copies at if/else joins); the masked loop selects per
+// logit in the causal instantiations and adds a key mask / ragged tail as a rank-1 MFMA per block in the non-causal ones (KM).
+// Grids that cannot fill the chip: the dQ kernel splits the key range, the dK/dV kernel the query range (gridDim.y, f32 slabs,
+// finalize kernel).
 #include <type_traits>
 
 #include "fcsa_common.cuh"

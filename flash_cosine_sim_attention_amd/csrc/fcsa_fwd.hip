@@ -24,14 +24,17 @@
 //     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read;
 //   * the key loop is split in two SEQUENTIAL loops, first the tiles that need no masking, then the
 //     tiles that do (key mask / tail / causal diagonal).  Each loop has one straight-line body, so the
-//     accumulators never cross an if/else join (which costs dozens of register copies per tile).
+//     accumulators never cross an if/else join (which costs dozens of register copies per tile).  The masked
+//     loop has two forms, fixed per kernel instantiation (KM): causal launches select per logit on their diagonal
+//     tiles, the others take a key mask / ragged tail as a rank-1 MFMA per block (key_mask_rank1, fcsa_common.cuh).
 //
 // Variants chosen by launch_forward (all parity-tested through the normal dispatch):
 //   fwd_kernel<.., NW = 4 | 8, ..>  two 128-row workgroups per CU, or one 256-row workgroup when the grid still covers the chip
 //   fwd_kernel<.., DYN>             per-row exponent reference for logit ranges no constant shift can hold (kept online, one pass)
 //   fwd_kernel, gridDim.y = splits  key range split over several workgroups + fwd_combine_kernel (grids that cannot fill the chip)
 //   fwd_kernel<.., LEAN>            16-bit D = 96 / 128 on chip-covering grids: no cross-block prefetch, 256 registers, two waves per SIMD
-//   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 64, 16 bit, no bias; see its header)
+//   fwd_kernel<.., KM>              non-causal launches: no causal pairing / diagonal logic, masked tiles in the rank-1 form
+//   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 64, 16 bit, no bias, no key mask; see its header)
 #include <cstdlib>
 #include <type_traits>
 
