@@ -16,10 +16,11 @@ DTYPES = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 
 def _c(name, b=1, h=2, n=63, m=None, d=32, dtype="f32", causal=False, mask=False, bias=False,
        bias_batch=False, single_kv=False, merged=False, scale=8, groups=1, l2norm=True,
-       mask_kind="random", tiled_ok=True, seed=0):
+       mask_kind="random", tiled_ok=True, seed=0, bias_std=1.0):
     return dict(name=name, b=b, h=h, n=n, m=(n if m is None else m), d=d, dtype=dtype, causal=causal,
                 mask=mask, bias=bias, bias_batch=bias_batch, single_kv=single_kv, merged=merged,
-                scale=scale, groups=groups, l2norm=l2norm, mask_kind=mask_kind, tiled_ok=tiled_ok, seed=seed)
+                scale=scale, groups=groups, l2norm=l2norm, mask_kind=mask_kind, tiled_ok=tiled_ok, seed=seed,
+                bias_std=bias_std)
 
 
 CASES = [
@@ -53,6 +54,16 @@ CASES = [
     _c("g22_mask_prefix_n150_m260_d64_f16", b=2, h=1, d=64, n=150, m=260, mask=True, mask_kind="prefix",
        dtype="f16", seed=22),
     _c("g23_merged_biasB_mask_d64_f32", b=2, d=64, n=63, merged=True, bias=True, mask=True, seed=23),
+    # --- round 3: the shapes its changes are about ----------------------------------------------
+    # float16 with a bias of sigma = 3 at scale 1: the configuration class whose P~ overflowed with a constant exponent shift
+    _c("g24_dense_biasH_std3_scale1_d64_f16", d=64, n=63, m=100, bias=True, bias_std=3.0, scale=1, dtype="f16", seed=24),
+    # few keys, many queries (split-query dK/dV), key mask
+    _c("g25_mask_n1100_m70_d16_f32", h=1, d=16, n=1100, m=70, mask=True, seed=25),
+    # few queries, many keys (split-key forward / dQ), prefix mask
+    _c("g26_mask_prefix_n40_m1100_d16_f16", h=1, d=16, n=40, m=1100, mask=True, mask_kind="prefix", dtype="f16",
+       seed=26),
+    # ragged non-causal tiles at D = 96 with grouped l2norm (rank-1 tail masks)
+    _c("g27_dense_n200_m333_d96_groups2_bf16", h=1, d=96, n=200, m=333, groups=2, scale=4, dtype="bf16", seed=27),
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}
@@ -94,4 +105,6 @@ def make_inputs(case, device="cpu"):
     if case["bias"]:
         lead = b if (case["bias_batch"] or case["merged"]) else h
         bias = t(lead, n, m)
+        if case.get("bias_std", 1.0) != 1.0:
+            bias = (bias.float() * case["bias_std"]).to(dt)
     return dict(q=q, k=k, v=v, do=do, mask=mask, attn_bias=bias)
