@@ -46,9 +46,23 @@ constexpr int kDkv2WBytes = 128;     // same for the dKV kernel
 constexpr int kDqSub8 = 4;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
 constexpr int kDkvBmq8 = 128;        // staged query rows of the 8-wave dKV kernel
 constexpr int kDkvBmqWide = 64;      // staged query rows of the dKV kernel for 16-bit D >= 96 (LDS-DMA form)
+#ifndef FCSA_DKV_RING
+#define FCSA_DKV_RING 1
+#endif
+constexpr bool kDkvRing = FCSA_DKV_RING != 0;
+      // three-buffer ring + tile pipeline across the tile barrier (dkv_tile_pipe)
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_dkv[128];
 __device__ unsigned long long g_trace_dq[128];
+#endif
+#ifdef FCSA_TRACE_BAR      // per wave of one workgroup: ticks spent at the tile barrier / in the tile loops (two s_memtime per tile, nothing else)
+__device__ unsigned long long g_trace_bar_dkv[64];
+__device__ unsigned long long g_trace_bar_dq[64];
+#define FCSA_BAR_BEGIN(v) do { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v)); } while (0)
+#define FCSA_BAR_END(v, acc) do { unsigned long long e_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(e_)); acc += e_ - v; } while (0)
+#else
+#define FCSA_BAR_BEGIN(v) ((void)0)
+#define FCSA_BAR_END(v, acc) ((void)0)
 #endif
 #ifdef FCSA_TRACE_WG
 __device__ unsigned long long g_trace_wg_dkv[2048];      // per workgroup: [2 * id] = start time, [2 * id + 1] = end time (wave 0)
@@ -209,11 +223,12 @@ template <typename T, int D, int NW, int SUB, bool TWO> struct DqLds
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
 // LEAN (16-bit rows of 129 .. 256 bytes, two waves per SIMD): the V rows of the workgroup's own keys live in the LDS behind the staging
 // buffers instead of in registers (VOWN bytes); the epilogue scratch then shares those bytes (never "SEP").
-template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false> struct DkvLds
-    : EpiLds<T, D, NW, 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4) + (LEAN ? 32 * NW * TileGeom<D, Traits<T>::ES>::ROWB : 0),
-             !LEAN && Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
+// NBUF: staging buffers -- 2, or 3 in the ring form (dkv_ring: the tile after the current one is always complete in the LDS).
+template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false, int NBUF = 2> struct DkvLds
+    : EpiLds<T, D, NW, NBUF * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4) + (LEAN ? 32 * NW * TileGeom<D, Traits<T>::ES>::ROWB : 0),
+             NBUF == 2 && !LEAN && Traits<T>::ES == 2 && !BIAS && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0,
              ((NW == 8 || (D * Traits<T>::ES > kDkv2WBytes && !LEAN)) ? 160 : 80) * 1024> {
-  static constexpr int VOWN = 2 * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);      // byte offset of the own-V tile (LEAN)
+  static constexpr int VOWN = NBUF * (2 * BMQ * TileGeom<D, Traits<T>::ES>::ROWB + 2 * BMQ * 4);      // byte offset of the own-V tile (LEAN)
 };
 
 // SUB = 64-key tiles per LDS stage: 1, or 2 / 4 in the 8-wave form (one workgroup per CU has the LDS for 128- / 256-key stages).
@@ -346,6 +361,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
       EP::load_inv(rinv_n, p.rq + (((int64_t)b_ * p.H + h_) * p.N + m0_ + wave * 32) * p.G, p.G, p.lgm, ln, rows_valid_);
   };
 
+#ifdef FCSA_TRACE_BAR
+  unsigned long long bar_wait = 0, bar_loop = 0;
+#endif
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
   int m0, nt;
@@ -440,6 +458,10 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     t_split = min(t_split, nt);
   }
 
+#ifdef FCSA_TRACE_BAR
+  unsigned long long bar_t = 0, loop_t = 0;
+  FCSA_BAR_BEGIN(loop_t);
+#endif
   DqPipe<T, D> pipe;
   pipe.tile = -1;
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
@@ -479,6 +501,10 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
         }
       }
       FCSA_STAMP(ts, 1);
+      if constexpr (kPrioBwd == 1 && NW == 8 && SUB >= 2) {
+        if (sub == 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+        if (sub == SUB / 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
+      }
       if constexpr (TR::ES == 2 && !BIAS && !TWO) {      // pipelined tile: one wave per SIMD only
         bool skip = false;
         if constexpr (MASKED) skip = causal && (j0 > mw + 31 + diff);
@@ -502,7 +528,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
           }
         }
         FCSA_STAMP(ts, 3);
+        FCSA_BAR_BEGIN(bar_t);
         __syncthreads();
+        FCSA_BAR_END(bar_t, bar_wait);
       }
       FCSA_STAMP(ts, 4);
       if constexpr (!MASKED) ts.close(4);
@@ -513,6 +541,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   FCSA_PASS_MARK(2);
   run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
   FCSA_PASS_MARK(3);
+#ifdef FCSA_TRACE_BAR
+  FCSA_BAR_END(loop_t, bar_loop);
+#endif
 
   // Epilogue through the LDS (RowEpilogue): every stage ended with a barrier, so no wave still reads the staging buffers.
   // With SEP, what the NEXT iteration needs from memory is requested between the epilogue's steps -- after the accumulators went to
@@ -552,6 +583,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   FCSA_PASS_MARK(4);
   }   // pass
 #undef FCSA_PASS_MARK
+#ifdef FCSA_TRACE_BAR
+  if (blockIdx.x == gridDim.x / 2 + 3 && blockIdx.y == 0 && lane == 0) { g_trace_bar_dq[2 * wave] = bar_wait; g_trace_bar_dq[2 * wave + 1] = bar_loop; }
+#endif
 #ifdef FCSA_TRACE_WG
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) { g_trace_wg_dq[2 * blockIdx.x] = trace_t0; g_trace_wg_dq[2 * blockIdx.x + 1] = trace_now(); }
 #endif
@@ -872,22 +906,31 @@ struct DkvPipe {
   }
 };
 
-template <typename T, int D, int BMQ, int MODE>
+// RING (dkv_ring): the pipeline state crosses tile boundaries.  The staging buffers form a ring of three, so the NEXT tile (`nxt`: its
+// Q tile, dO tile at nxt + TILE_B, per-query terms behind them) is complete in the LDS while this one is processed: its first block's
+// fragments are requested during the last block's M2 products, i.e. BEFORE the tile barrier, and the first chains of a tile start
+// right behind it.  (Two buffers: that request sits at the top of the tile, exposed -- block 0 of a tile took 1320 ticks against 880
+// for the others, phase trace.)  `fresh`: nothing is in flight for this tile (first tile of a pass, or the previous one was skipped).
+template <typename T, int D, int BMQ, int MODE, bool RING = false>
 FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                             const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                             f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
-                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts) {
+                            uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts, DkvPipe<T, D, BMQ>& pp_, bool fresh = true,
+                            const char* nxt = nullptr, bool young = false) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
   constexpr int NB = BMQ / 32;
-  DkvPipe<T, D, BMQ> pp_;
-  pp_.request(qt, dot, lcs, dls, fa, 0);
+  if (!RING || fresh) pp_.request(qt, dot, lcs, dls, fa, 0);
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
     uint32_t w = 0xffffffffu;
     if constexpr (MASKED) w = kmask & (ge_mask(j - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm);
     FCSA_FENCE();
+    if constexpr (kPrioBwd == 1) {      // (`young` is wave-uniform and lives in an SGPR: a scalar branch around one s_setprio)
+      if (ib == 0) { if (young) __builtin_amdgcn_s_setprio(1); }
+      if (ib == NB / 2) { if (young) __builtin_amdgcn_s_setprio(0); }
+    }
     if (ib == 1) FCSA_STAMP(ts, 2);
     // ---- M1: S = Q K^T + lc, dP = dO V^T - delta (the per-query terms are the accumulators' initial values)
     f32x16 s = pp_.s, dp = pp_.dp;
@@ -924,8 +967,12 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     db_.prep(s);
     FCSA_FENCE();
     if (ib == 1) FCSA_STAMP(ts, 4);
-    // ---- R: next block's row fragments (their registers are dead now)
+    // ---- R: next block's row fragments (their registers are dead now); RING: behind the last block, block 0 of the next tile
     if (ib + 1 < NB) pp_.request(qt, dot, lcs, dls, fa, ib + 1);
+    else if constexpr (RING) {
+      constexpr int TB = BMQ * G::ROWB;
+      pp_.request(nxt, nxt + TB, reinterpret_cast<const float*>(nxt + 2 * TB), reinterpret_cast<const float*>(nxt + 2 * TB) + BMQ, fa, 0);
+    }
     // ---- M2: dV^T += dO^T P, dK^T += Q^T dS
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
@@ -937,7 +984,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
       dk[db] = TR::mfma32(tq[db][0], db_.v[0], dk[db]);
       dk[db] = TR::mfma32(tq[db][1], db_.v[1], dk[db]);
     }
-    if (ib + 1 < NB) {      // spread the R requests behind the first M2 MFMAs (hipcc otherwise sinks them below the products)
+    if (ib + 1 < NB || RING) {      // spread the R requests behind the first M2 MFMAs (hipcc otherwise sinks them below the products)
       constexpr int NM2 = 4 * G::DB, NR = 8 + 2 * G::KS;
 #pragma unroll
       for (int m = 0; m < NM2; ++m) {
@@ -949,7 +996,8 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
   }
 }
 
-template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)
+// RING: three staging buffers instead of two and the tile pipeline crosses the tile barrier (dkv_tile_pipe); pipelined LDS-DMA form only
+template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM, bool RING = false>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes || LEAN) ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
@@ -959,8 +1007,10 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   static_assert(!LEAN || (Traits<T>::ES == 2 && !BIAS), "lean form: 16-bit types without bias");
   constexpr bool PIPE = Traits<T>::ES == 2 && !BIAS && !LEAN;      // software-pipelined tile (dkv_tile_pipe)
   constexpr int BUF_B = 2 * TILE_B + 2 * BMQ * 4;                // Q tile | dO tile | lc[BMQ] | -delta[BMQ]
+  constexpr int NBUF = RING ? 3 : 2;
   static_assert(BMQ % 32 == 0 && BMQ <= NT, "query tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF_B]
+  static_assert(!RING || PIPE, "ring form: pipelined LDS-DMA tile only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF_B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1005,8 +1055,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
   // Q / dO tiles: LDS-DMA in the pipelined form (no staging registers, no ds_write passes), else through registers
   constexpr bool DMA = (PIPE || LEAN) && (BMQ * G::ROWB) % 1024 == 0;
-  typedef DkvLds<T, D, NW, BMQ, BIAS, LEAN> LDS;
+  typedef DkvLds<T, D, NW, BMQ, BIAS, LEAN, NBUF> LDS;
   constexpr bool SEP = LDS::SEP;      // see bwd_dq_kernel: the next pass is requested from inside the epilogue of the current one
+  static_assert(!RING || (DMA && !SEP), "ring form");
   Stager<T, D, BMQ, NT> sq, sdo;
   typedef DmaStager<T, D, DMA ? BMQ : 1024, NW> DS;
   DS dq_, ddo_;
@@ -1026,6 +1077,8 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   }
   float lc_r = 0.f, dl_r = 0.f;
   bool row_ok = false;
+  float lc_r2 = 0.f, dl_r2 = 0.f;      // RING: the pass prologue stages two tiles
+  bool row_ok2 = false;
   auto load_rows = [&](int i0) {      // per-query terms of a tile; raw loads only: any arithmetic on them here would force an immediate vmcnt wait
     if (tid < BMQ) {
       const int i = min(i0 + tid, p.N - 1);
@@ -1075,6 +1128,19 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
         ddo_.issue(stdo, lds0 + TILE_B, wave);
         load_rows(t0_ * BMQ);
       }
+      if constexpr (RING) {      // second tile of the pass -> buffer 1 (its per-query terms travel in the second register set)
+        if (t0_ + 1 < QT) {
+          advance(t0_ + 1);
+          dq_.issue(stq, lds0 + BUF_B, wave);
+          ddo_.issue(stdo, lds0 + BUF_B + TILE_B, wave);
+          if (tid < BMQ) {
+            const int i = min((t0_ + 1) * BMQ + tid, p.N - 1);
+            lc_r2 = invl_row[i];
+            dl_r2 = delta_row[i];
+            row_ok2 = (t0_ + 1) * BMQ + tid < p.N;
+          }
+        }
+      }
     }
     if constexpr (LEAN) {      // the V rows of this workgroup's keys -> LDS (rows past M are zero-filled by the descriptor's range check)
       DmaStager<T, D, BNK, NW> dvown_;      // (set up here, once per pass, from an opaque lane id: nothing of it lives across the tile loops)
@@ -1103,6 +1169,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
     }
   };
 
+#ifdef FCSA_TRACE_BAR
+  unsigned long long bar_wait = 0, bar_loop = 0;
+#endif
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
   int n0, t0;
@@ -1166,6 +1235,13 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
   if (t0 < QT) store_tile(smem);
+  if constexpr (RING) {      // per-query terms of the pass's second tile (its DMA was covered by the wait above)
+    if (t0 + 1 < QT && tid < BMQ) {
+      char* buf1 = smem + BUF_B;
+      reinterpret_cast<float*>(buf1 + 2 * TILE_B)[tid] = row_ok2 ? (p.invl_log2 ? lc_r2 : __builtin_amdgcn_logf(lc_r2)) - p.c2 : -INFINITY;
+      reinterpret_cast<float*>(buf1 + 2 * TILE_B + BMQ * 4)[tid] = row_ok2 ? -dl_r2 : 0.f;
+    }
+  }
   if constexpr (LEAN) dma_wait();      // the own-V tile (also on the no-tile path: its bytes are the epilogue's scratch)
   __syncthreads();
   // Every prologue load (Q / dO / K / V fragments, first tile) is complete on the real path; say so on ALL paths.
@@ -1182,25 +1258,37 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
     if (causal) t_m = min(QT, max(t0, (nw + 31 - diff + BMQ - 1) / BMQ));
   }
 
+#ifdef FCSA_TRACE_BAR
+  unsigned long long bar_t = 0, loop_t = 0;
+  FCSA_BAR_BEGIN(loop_t);
+#endif
+  DkvPipe<T, D, BMQ> pipe;      // RING: lives across the tiles of a pass
+  int pipe_tile = -1;           // RING: the tile whose first block's fragments are in flight
+  int ring = 0;                 // RING: staging buffer of the current tile (t - t0 mod 3, kept without a division)
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
     constexpr int MODE = decltype(masked_tag)::value;      // dkv_tile: 0 all valid, 1 causal select, 2 key mask by rank-1 MFMA
     constexpr bool MASKED = MODE != 0;
     for (int t = t_begin; t < t_end; ++t) {
       const int i0 = t * BMQ;
-      const int par = (t - t0) & 1;
+      // two buffers: the next tile lands in the other one during this tile.  RING: tile t + 1 is complete already (requested at the
+      // top of tile t - 1, or in the pass prologue); tile t + 2 is requested here into the buffer tile t - 1 has left
+      const int par = RING ? ring : (t - t0) & 1;
+      const int par_nxt = RING ? (ring == 2 ? 0 : ring + 1) : (par ^ 1);          // buffer of tile t + 1
+      const int par_ld = RING ? (ring == 0 ? 2 : ring - 1) : (par ^ 1);           // buffer this tile's requests fill
+      const int t_ld = RING ? t + 2 : t + 1;                                      // ... with this tile
       const char* cur = smem + par * BUF_B;
-      char* nxt = smem + (par ^ 1) * BUF_B;
-      const bool more = t + 1 < QT;
+      char* nxt = smem + par_ld * BUF_B;
+      const bool more = t_ld < QT;
       FCSA_STAMP(ts, 0);
       const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
       const float* dls = lcs + BMQ;
       if constexpr (DMA) {
         // the next tile arrives by LDS-DMA, all pieces requested at the top of this tile
         if (more) {
-          advance(t + 1);
-          load_rows(i0 + BMQ);
+          advance(t_ld);
+          load_rows(t_ld * BMQ);
         }
-        const uint32_t lds_nxt = lds0 + (par ^ 1) * BUF_B;
+        const uint32_t lds_nxt = lds0 + par_ld * BUF_B;
         FCSA_STAMP(ts, 1);
         if (more) {
           dq_.issue(stq, lds_nxt, wave);
@@ -1214,7 +1302,18 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       bool skip = false;
       if constexpr (MASKED) skip = causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
       if constexpr (PIPE) {
-        if (!skip) dkv_tile_pipe<T, D, BMQ, MODE>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts);
+        if constexpr (RING) {
+          if (!skip) {
+            const bool has_next = t + 1 < QT;      // (else: the request reads this tile's buffer again and is never used)
+            dkv_tile_pipe<T, D, BMQ, MODE, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, pipe_tile != t,
+                                                  has_next ? smem + par_nxt * BUF_B : cur, NW == 8 && wave >= 4);
+            pipe_tile = has_next ? t + 1 : -1;
+          }
+          ring = par_nxt;
+        } else {
+          if (!skip) dkv_tile_pipe<T, D, BMQ, MODE>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, true, nullptr,
+                                                    NW == 8 && wave >= 4);
+        }
       } else if constexpr (LEAN) {
         if (!skip) dkv_tile<T, D, BMQ, MODE, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
                                                             bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32);
@@ -1231,7 +1330,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       FCSA_STAMP(ts, 8);
       if (more) store_tile(nxt);
       FCSA_STAMP(ts, 9);
+      FCSA_BAR_BEGIN(bar_t);
       __syncthreads();
+      FCSA_BAR_END(bar_t, bar_wait);
       FCSA_STAMP(ts, 10);
       if constexpr (!MASKED) ts.close(10);
     }
@@ -1241,6 +1342,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   FCSA_PASS_MARK(2);
   run(std::integral_constant<int, 0>{}, t_m, QT);
   FCSA_PASS_MARK(3);
+#ifdef FCSA_TRACE_BAR
+  FCSA_BAR_END(loop_t, bar_loop);
+#endif
 
   // Epilogue through the LDS (RowEpilogue): every tile ended with a barrier, so no wave still reads the staging buffers.
   // With SEP the next pass is requested between its steps and the epilogue reads nothing from global memory (see bwd_dq_kernel).
@@ -1283,6 +1387,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   FCSA_PASS_MARK(4);
   }   // pass
 #undef FCSA_PASS_MARK
+#ifdef FCSA_TRACE_BAR
+  if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) { g_trace_bar_dkv[2 * wave] = bar_wait; g_trace_bar_dkv[2 * wave + 1] = bar_loop; }
+#endif
 #ifdef FCSA_TRACE_WG
   if (tid == 0 && blockIdx.x < 1024) { g_trace_wg_dkv[2 * blockIdx.x] = trace_t0; g_trace_wg_dkv[2 * blockIdx.x + 1] = trace_now(); }
 #endif
@@ -1309,6 +1416,16 @@ extern "C" int fcsa_trace_read_pass_dkv(unsigned long long* out) {
 }
 extern "C" int fcsa_trace_read_wg_dkv(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_wg_dkv), sizeof(unsigned long long) * 2048);
+}
+namespace fcsa {
+#endif
+#ifdef FCSA_TRACE_BAR
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_bar_dkv(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_bar_dkv), sizeof(unsigned long long) * 64);
+}
+extern "C" int fcsa_trace_read_bar_dq(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_bar_dq), sizeof(unsigned long long) * 64);
 }
 namespace fcsa {
 #endif
@@ -1386,16 +1503,19 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr int BMQ = LEAN ? LEAN_BMQ : (D * Traits<T>::ES >= 192) ? (DMA_FORM ? kDkvBmqWide : 32) : (NW == 8 ? kDkvBmq8 : 64);
   const int KT = (p.M + BNK - 1) / BNK;
   const int PT = p.causal ? (KT + 1) / 2 : KT;
-  // 2 x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
-  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
+  // ring form: the pipelined LDS-DMA tile (16 bit, no bias, not lean) where three buffers fit the workgroup's LDS share
+  constexpr bool RING = kDkvRing && DMA_FORM && !LEAN && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0 &&
+                        DkvLds<T, D, NW, BMQ, BIAS, LEAN, 3>::TOTAL <= ((NW == 8 || D * Traits<T>::ES > kDkv2WBytes) ? 160 : 80) * 1024;
+  // NBUF x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
+  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN, RING ? 3 : 2>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
   const dim3 grid((unsigned)(p.B * p.H * PT), (unsigned)(p.dkv_splits > 1 ? p.dkv_splits : 1));
   if (p.causal) {        // (two instantiations, see launch_fwd_nw)
-    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, false>;
+    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, false, RING>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
   } else {
-    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, true>;
+    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, true, RING>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);

@@ -112,10 +112,15 @@ constexpr float kStaticTop = 65.f, kStaticBottom = 85.f;      // exp(s - shift) 
 // shift; a strongly negative bias underflows to an exact 0 weight).  f16 does not: its static shift puts the largest logit at e^10 of a
 // 65504 range, so a bias of +1.1 on such a logit overflowed P~ to inf (found by an exploratory fuzz seed in round 3: f16, scale 1, bias
 // ~ N(0, 0.5)).  f16 problems WITH a bias therefore always take the per-row-reference form (whose online max includes the bias).
+// bf16 / f32 WITH a bias: the "+-20 around any shift" only holds while the window is not used up by the logits themselves; for
+// 60 < bound <= 75 a positive bias on a logit near the bound has e^23 ... e^8 of headroom before P~ or the row sum reach f32's top
+// (inf -> NaN rows), so those problems take the per-row form as well (round 3 review).
+constexpr float kStaticBoundBias = 60.f;
 bool dynamic_shift(const fcsa_problem& p, bool has_bias) {
   if (!p.l2norm_qk) return false;
   const float bound = fabsf(p.scale) * (float)p.groups;
-  return p.dtype == FCSA_F16 ? (has_bias || bound > 11.f) : 2.f * bound > kStaticTop + kStaticBottom;
+  if (p.dtype == FCSA_F16) return has_bias || bound > 11.f;
+  return 2.f * bound > kStaticTop + kStaticBottom || (has_bias && bound > kStaticBoundBias);
 }
 
 float exponent_shift(const fcsa_problem& p, bool has_bias) {

@@ -149,6 +149,23 @@ template <typename T> FCSA_DEV f32x16 key_mask_rank1_cols(f32x16 c, bool key_mas
   }
 }
 
+// Wave priority inside a barrier interval.  The two waves of a SIMD are arbitrated by priority, then AGE: the first-dispatched half of
+// an 8-wave workgroup (waves 0-3) wins every conflict, finishes its share of a barrier interval early and then idles ~30 % of the tile
+// loop at the barrier (-DFCSA_TRACE_BAR, tools/trace_bar.py: waves 0-3 wait 29 - 33 % of the dK/dV and dQ loops, waves 4-7 4 - 6 %) while
+// its partner, which was held back, finishes alone at the one-wave rate.  kPrioBwd: the younger half runs at priority 1 during the
+// FIRST half of its blocks of an interval and at 0 afterwards, so each half is favoured for about half of the interval and both reach
+// the barrier together (waits 7 - 9 % / 6 %; tile loops of dK/dV -10.7 %, of dQ -4.1 % in clocks).  The forward keeps age order
+// (kPrioFwd = 0): its interval is one 64-key tile with the barrier in its middle, and the balanced form measured +10 % clocks there --
+// the old half running ahead is what puts its MFMA phases beside the young half's exponentials.
+#ifndef FCSA_PRIO_BWD
+#define FCSA_PRIO_BWD 1
+#endif
+#ifndef FCSA_PRIO_FWD
+#define FCSA_PRIO_FWD 0
+#endif
+constexpr int kPrioBwd = FCSA_PRIO_BWD;
+constexpr int kPrioFwd = FCSA_PRIO_FWD;
+
 // A value the optimiser must treat as freshly computed here: keeps per-lane address arithmetic of prologues / epilogues from being
 // hoisted out of the pass loop, where it would stay live across the tile loops and push the kernels over their register budget
 // (observed: 10 hoisted address pairs spilled to scratch and reloaded -- a memory round trip each -- in the dQ epilogue).

@@ -48,6 +48,14 @@ constexpr int kFwdSub = 1;
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
 #endif
+#ifdef FCSA_TRACE_BAR      // see fcsa_bwd.hip
+__device__ unsigned long long g_trace_bar_fwd[64];
+#define FCSA_BAR_BEGIN(v) do { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v)); } while (0)
+#define FCSA_BAR_END(v, acc) do { unsigned long long e_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(e_)); acc += e_ - v; } while (0)
+#else
+#define FCSA_BAR_BEGIN(v) ((void)0)
+#define FCSA_BAR_END(v, acc) ((void)0)
+#endif
 #ifdef FCSA_TRACE_WG
 __device__ unsigned long long g_trace_wg_fwd[2048];      // per workgroup: [2 * id] = start time, [2 * id + 1] = end time (wave 0)
 __device__ unsigned long long g_trace_pass_fwd[2560];     // per workgroup (first 256): [pass][5] pass marks of wave 0
@@ -562,6 +570,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
 #else
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
+#ifdef FCSA_TRACE_BAR
+  unsigned long long bar_wait = 0, bar_loop = 0;
+#endif
   for (int pass = 0; pass < npass; ++pass) {
   FCSA_PASS_MARK(0);
   const int mt = causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
@@ -700,6 +711,10 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
     t_split = min(t_split, nt);
   }
 
+#ifdef FCSA_TRACE_BAR
+  unsigned long long bar_t = 0, loop_t = 0;
+  FCSA_BAR_BEGIN(loop_t);
+#endif
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
     constexpr int MODE = decltype(masked_tag)::value;      // fwd_tile: 0 all valid, 1 causal select, 2 key mask by rank-1 MFMA
     constexpr bool MASKED = MODE != 0;
@@ -714,6 +729,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       char* knxt = smem + (sub + 1 < SUB ? (u & 1) * STAGE_B + (sub + 1) * TILE_B : ((u + 1) & 1) * STAGE_B);
       const bool last_of_stage = sub == SUB - 1 || t + 1 >= nt;   // workgroup-uniform
       FCSA_STAMP(ts, 0);
+      if constexpr (kPrioFwd == 1 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
       uint64_t word = 0;
       if constexpr (MASKED) {
         // consume the mask byte loaded one tile ago BEFORE issuing new loads (its wait then covers nothing else)
@@ -753,7 +769,12 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         FCSA_STAMP(ts, 5);
         if (last_of_stage) {
           if constexpr (DMA) dma_wait();
+          FCSA_BAR_BEGIN(bar_t);
           __syncthreads();
+          FCSA_BAR_END(bar_t, bar_wait);
+          // (kPrioFwd: the younger half of the workgroup is favoured from the barrier to the end of the tile, the older half -- by age --
+          //  from the top of the next tile to the barrier; see fcsa_common.cuh)
+          if constexpr (kPrioFwd == 1 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
         }
         FCSA_STAMP(ts, 6);
       };
@@ -779,6 +800,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   run(std::integral_constant<int, 0>{}, 0, t_split);
   run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
   FCSA_PASS_MARK(3);
+#ifdef FCSA_TRACE_BAR
+  FCSA_BAR_END(loop_t, bar_loop);
+#endif
   // no trailing barrier: every wave completed its last LDS read before the final mid() barrier, so the next
   // pass may overwrite buffer 0 in its prologue
 
@@ -808,6 +832,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   }
   FCSA_PASS_MARK(4);
   }   // pass
+#ifdef FCSA_TRACE_BAR
+  if (blockIdx.x == gridDim.x / 2 + 3 && blockIdx.y == 0 && lane == 0) { g_trace_bar_fwd[2 * wave] = bar_wait; g_trace_bar_fwd[2 * wave + 1] = bar_loop; }
+#endif
 #ifdef FCSA_TRACE_WG
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024) { g_trace_wg_fwd[2 * blockIdx.x] = trace_t0; g_trace_wg_fwd[2 * blockIdx.x + 1] = trace_now(); }
 #endif
@@ -823,6 +850,13 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
 #endif
 }
 
+#ifdef FCSA_TRACE_BAR
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_bar_fwd(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_bar_fwd), sizeof(unsigned long long) * 64);
+}
+namespace fcsa {
+#endif
 #ifdef FCSA_TRACE_WG
 }  // namespace fcsa
 extern "C" int fcsa_trace_read_pass_fwd(unsigned long long* out) {

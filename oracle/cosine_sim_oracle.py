@@ -25,8 +25,44 @@ import numpy as np
 __all__ = [
     "l2norm", "l2norm_backward", "plain_attention", "tiled_attention",
     "attention_forward_stats", "attention_backward", "causal_valid_count",
-    "algorithmic_flops",
+    "algorithmic_flops", "round_to", "rounded_operands",
 ]
+
+LOG2E = 1.4426950408889634
+
+
+# ----------------------------------------------------------------------------
+# 16-bit operand rounding ("operand-faithful" evaluation)
+# ----------------------------------------------------------------------------
+
+def round_to(x: np.ndarray, dtype_name: str | None) -> np.ndarray:
+    """x rounded to `dtype_name` ("bf16" | "f16" | "f32" | None) with round-to-nearest-even, returned as float64."""
+    x = np.asarray(x, dtype=np.float64)
+    if dtype_name in (None, "f64"):
+        return x
+    if dtype_name == "f32":
+        return x.astype(np.float32).astype(np.float64)
+    if dtype_name == "f16":
+        return x.astype(np.float16).astype(np.float64)
+    if dtype_name == "bf16":
+        f = np.ascontiguousarray(x.astype(np.float32))
+        u = f.view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)      # RNE on the upper 16 bits (finite values)
+        out = r.view(np.float32).astype(np.float64)
+        return np.where(np.isfinite(f), out, f.astype(np.float64))
+    raise ValueError(dtype_name)
+
+
+def rounded_operands(qh, kh, scale, operand_dtype):
+    """The operands every 16-bit implementation of this op feeds its S product (the reference's too: it normalises in the input
+    dtype, fcsa.py:57-65): kh rounded to the dtype, and qh rounded AFTER folding c1 = scale * log2(e) in, as the gfx950 kernels
+    do (they compute exp2(c1 qh . kh - c2)); returned in qh's units.  Exact arithmetic on THESE operands is the "operand-faithful"
+    reference: it leaves out the one error every implementation shares and that grows with the logit range scale * groups."""
+    if operand_dtype in (None, "f64", "f32"):
+        return qh, kh
+    c1 = abs(float(scale)) * LOG2E
+    c1 = c1 if c1 > 0 else 1.0
+    return round_to(qh * c1, operand_dtype) / c1, round_to(kh, operand_dtype)
 
 
 # ----------------------------------------------------------------------------
@@ -53,7 +89,7 @@ def l2norm(x: np.ndarray, groups: int = 1, eps: float = 1e-12, return_inv_norm: 
     return out
 
 
-def l2norm_backward(dxhat: np.ndarray, x: np.ndarray, groups: int = 1, eps: float = 1e-12) -> np.ndarray:
+def l2norm_backward(dxhat: np.ndarray, x: np.ndarray, groups: int = 1, eps: float = 1e-12, xh_used: np.ndarray | None = None) -> np.ndarray:
     """Gradient of `l2norm` w.r.t. x given the gradient w.r.t. its output.
 
     The reference leaves this to torch.autograd through F.normalize
@@ -61,6 +97,8 @@ def l2norm_backward(dxhat: np.ndarray, x: np.ndarray, groups: int = 1, eps: floa
     per group, with n = max(||x||, eps) and xh = x / n,
         dx = (dxh - xh <dxh, xh>) / n      if ||x|| > eps
         dx = dxh / eps                     otherwise (clamp has zero slope)
+    xh_used: the normalised rows an implementation actually holds (e.g. rounded to 16 bit, `rounded_operands`) and uses in the
+    projection instead of the exact x / n.
     """
     shape = x.shape
     d = shape[-1]
@@ -69,6 +107,8 @@ def l2norm_backward(dxhat: np.ndarray, x: np.ndarray, groups: int = 1, eps: floa
     norm = np.sqrt((xg ** 2).sum(-1, keepdims=True))
     n = np.maximum(norm, eps)
     xh = xg / n
+    if xh_used is not None:
+        xh = np.asarray(xh_used, dtype=np.float64).reshape(xg.shape)
     dot = (dg * xh).sum(-1, keepdims=True)
     dx = np.where(norm > eps, (dg - xh * dot) / n, dg / eps)
     return dx.reshape(shape)
@@ -149,11 +189,12 @@ def plain_attention(q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causa
 # ----------------------------------------------------------------------------
 
 def attention_forward_stats(q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
-                            l2norm_qk=True, attn_bias_batch_dim=False, dtype=np.float64, eps=1e-10):
+                            l2norm_qk=True, attn_bias_batch_dim=False, dtype=np.float64, eps=1e-10, operand_dtype=None):
     """Un-tiled statement of the kernel math: returns (o, inv_l) with
     P~ = valid ? exp(S - scale) : 0 (cu:1216), l = rowsum(P~), inv_l = 1/max(l, eps)
     (cu:1236-1242, eps = 1e-10 cu:83), o = inv_l * P~ V (cu:1244).
     Rows with no valid key give o = 0 (kernel behaviour), unlike `plain_attention`.
+    operand_dtype ("bf16" | "f16"): exact arithmetic on the 16-bit operands of the S product (`rounded_operands`).
     """
     assert not (causal and mask is not None)
     q, k, v = (np.asarray(t, dtype=dtype) for t in (q, k, v))
@@ -162,6 +203,7 @@ def attention_forward_stats(q, k, v, mask=None, attn_bias=None, scale=8, groups=
     q, k, v, attn_bias, merged = _canon(q, k, v, attn_bias, attn_bias_batch_dim)
     if l2norm_qk:
         q, k = l2norm(q, groups), l2norm(k, groups)
+    q, k = rounded_operands(q, k, scale, operand_dtype)
     h = q.shape[1]
     kb = np.broadcast_to(k, (k.shape[0], h) + k.shape[2:])
     vb = np.broadcast_to(v, (v.shape[0], h) + v.shape[2:])
@@ -239,7 +281,7 @@ def tiled_attention(q, k, v, mask=None, attn_bias=None, scale=8, causal=False,
 # ----------------------------------------------------------------------------
 
 def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
-                       l2norm_qk=True, attn_bias_batch_dim=False, dtype=np.float64, eps=1e-10):
+                       l2norm_qk=True, attn_bias_batch_dim=False, dtype=np.float64, eps=1e-10, operand_dtype=None):
     """Analytic gradients (dq, dk, dv, d_bias) w.r.t. the RAW q, k, v, bias.
 
     Kernel math (w.r.t. the normalised qh, kh):
@@ -251,6 +293,8 @@ def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1
         dQh = scale * dS Kh ; dKh = scale * dS^T Qh   cu:1580-1610
     then chained through `l2norm_backward` when l2norm_qk (autograd does this in
     the reference because l2norm sits outside the Function, fcsa.py:320-321).
+    operand_dtype ("bf16" | "f16"): the same formulas in exact arithmetic on the 16-bit normalised operands (`rounded_operands`),
+    which also stand in for x / n in the l2norm backward -- the gradient a 16-bit implementation computes, minus its own roundings.
     """
     assert not (causal and mask is not None)
     q0, k0, v0 = (np.asarray(t, dtype=dtype) for t in (q, k, v))
@@ -261,6 +305,8 @@ def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1
         do = do[:, None]
         attn_bias_batch_dim = True
     qh, kh = (l2norm(qc, groups), l2norm(kc, groups)) if l2norm_qk else (qc, kc)
+    qh, kh = rounded_operands(qh, kh, scale, operand_dtype)
+    faithful = operand_dtype in ("bf16", "f16")
     b, h, n, d = qh.shape
     m = kh.shape[2]
     hk = kh.shape[1]
@@ -287,8 +333,8 @@ def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1
     dbias = None
     if bias is not None:
         dbias = ds.sum(1) if attn_bias_batch_dim else ds.sum(0)
-    dq = l2norm_backward(dqh, qc, groups) if l2norm_qk else dqh
-    dk = l2norm_backward(dkh, kc, groups) if l2norm_qk else dkh
+    dq = l2norm_backward(dqh, qc, groups, xh_used=qh if faithful else None) if l2norm_qk else dqh
+    dk = l2norm_backward(dkh, kc, groups, xh_used=kh if faithful else None) if l2norm_qk else dkh
     dq = dq.reshape(q0.shape)
     dk = dk.reshape(k0.shape)
     dv = dv.reshape(v0.shape)

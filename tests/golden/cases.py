@@ -16,11 +16,11 @@ DTYPES = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 
 def _c(name, b=1, h=2, n=63, m=None, d=32, dtype="f32", causal=False, mask=False, bias=False,
        bias_batch=False, single_kv=False, merged=False, scale=8, groups=1, l2norm=True,
-       mask_kind="random", tiled_ok=True, seed=0, bias_std=1.0):
+       mask_kind="random", tiled_ok=True, seed=0, bias_std=1.0, wide=False):
     return dict(name=name, b=b, h=h, n=n, m=(n if m is None else m), d=d, dtype=dtype, causal=causal,
                 mask=mask, bias=bias, bias_batch=bias_batch, single_kv=single_kv, merged=merged,
                 scale=scale, groups=groups, l2norm=l2norm, mask_kind=mask_kind, tiled_ok=tiled_ok, seed=seed,
-                bias_std=bias_std)
+                bias_std=bias_std, wide=wide)
 
 
 CASES = [
@@ -64,9 +64,40 @@ CASES = [
        seed=26),
     # ragged non-causal tiles at D = 96 with grouped l2norm (rank-1 tail masks)
     _c("g27_dense_n200_m333_d96_groups2_bf16", h=1, d=96, n=200, m=333, groups=2, scale=4, dtype="bf16", seed=27),
+    # --- round 4: wide logit ranges (`wide`: the 16-bit rounding of q^, k^ is amplified by scale * groups, in the reference's own
+    # 16-bit evaluation too; tests compare twice -- against these fixtures with the bar times logit_cond(), and against exact
+    # arithmetic on the 16-bit operands (oracle operand_dtype) with the FIXED bar).  The reference's tiled CPU path and its kernel
+    # form exp(S - scale) leave float32 at these ranges (tiled_ok = False); plain_cosine_sim_attention is the reference here.
+    _c("g28_dense_groups8_scale8_n320_d64_bf16", h=1, d=64, n=320, groups=8, scale=8, dtype="bf16", tiled_ok=False, wide=True,
+       seed=28),                                                     # scale * groups = 64: top of the static bf16 window region
+    _c("g29_causal_groups8_scale12_n300_d128_bf16", h=1, d=128, n=300, groups=8, scale=12, causal=True, dtype="bf16",
+       tiled_ok=False, wide=True, seed=29),                          # 96: beyond the window, per-row online reference
+    _c("g30_mask_scale16_n320_m400_d64_f16", h=1, d=64, n=320, m=400, mask=True, scale=16, dtype="f16", tiled_ok=False, wide=True,
+       seed=30),                                                     # f16 beyond its window (11)
+    _c("g31_dense_biasH_std3_n300_m330_d64_f16", h=1, d=64, n=300, m=330, bias=True, bias_std=3.0, dtype="f16", tiled_ok=False,
+       wide=True, seed=31),                                          # f16 + bias of sigma 3 at the default scale, N >= 300
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}
+
+
+def logit_cond(dtype, scale, groups, l2norm=True):
+    """Amplification of the 16-bit rounding of q^, k^ by the logit range: the logits are scale * sum_g cos_g with cos_g carrying
+    the 2^-9 (bf16) / 2^-12 (f16) rounding of the normalised operands -- which the reference rounds too -- so comparisons against
+    exact math ON THE RAW INPUTS scale their bar with max(1, scale * groups / 16); comparisons against exact math on the 16-bit
+    operands (oracle `operand_dtype`) do not."""
+    return max(1.0, abs(scale) * groups / 16.0) if (dtype != "f32" and l2norm) else 1.0
+
+
+def dynamic_shift_regime(dtype, scale, groups, l2norm, bias):
+    """fcsa_capi.hip dynamic_shift(): logit ranges no constant exponent shift can hold run the per-row online reference and are
+    normalised exactly (no 1e-10 clamp in exp(S - scale) units, like the reference's plain_cosine_sim_attention)."""
+    bound = abs(scale) * groups
+    if not l2norm:
+        return False
+    if dtype == "f16":
+        return bound > 11 or bool(bias)
+    return bound > 75 or (bool(bias) and bound > 60)
 
 
 def op_kwargs(case):

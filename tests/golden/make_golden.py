@@ -44,7 +44,10 @@ def load_reference():
 def main():
     ref = load_reference()
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])                     # optional: case-name prefixes (e.g. g28 g29) -- the other files stay untouched
     for case in C.CASES:
+        if only and not any(case["name"].startswith(p) for p in only):
+            continue
         inp = C.make_inputs(case)               # dict of torch tensors in the case dtype
         kw = C.op_kwargs(case)
         f64 = {n: (t.double() if t is not None and t.is_floating_point() else t) for n, t in inp.items()}

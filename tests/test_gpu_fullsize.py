@@ -46,6 +46,44 @@ def _ref_slice(q, k, v, mask, causal, scale, groups, ref_dtype=torch.float32, op
     return torch.softmax(s, dim=-1) @ v
 
 
+def _grads_operand_faithful(q, k, v, do, mask, causal, scale, groups, dtype):
+    """Gradients of one (batch, head) slice by the kernel's own formulas in float64 on the 16-bit OPERANDS:
+    c1 * q^ and k^ rounded to `dtype` feed S, dQ^ = scale dS K^, dK^ = scale dS^T Q^ and the projection of the l2norm backward
+    (what oracle.attention_backward(operand_dtype=...) computes, here in torch on the GPU so that full-size slices take
+    milliseconds).  Returns (dq, dk, dv) w.r.t. the raw slices; pinned to the numpy oracle by test_operand_faithful_helper..."""
+    q, k, v, do = (t.double() for t in (q, k, v, do))
+    n, d = q.shape
+    m = k.shape[0]
+
+    def nrm(t):
+        tg = t.reshape(t.shape[0], groups, d // groups)
+        inv = 1.0 / tg.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        return (tg * inv).reshape(t.shape), inv
+
+    qn, rq = nrm(q)
+    kn, rk = nrm(k)
+    c1 = abs(scale) * 1.4426950408889634
+    qr = (qn * c1).to(dtype).double() / c1
+    kr = kn.to(dtype).double()
+    s = (qr @ kr.t()) * scale
+    if causal:
+        s = s.masked_fill(torch.ones(n, m, dtype=torch.bool, device=s.device).triu(m - n + 1), float("-inf"))
+    if mask is not None:
+        s = s.masked_fill(~mask[None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = p @ v
+    delta = (do * o).sum(-1, keepdim=True)
+    dv = p.t() @ do
+    ds = p * (do @ v.t() - delta)
+    dqh, dkh = scale * (ds @ kr), scale * (ds.t() @ qr)
+
+    def nrm_bwd(g, xh, inv):
+        gg, xg = g.reshape(g.shape[0], groups, -1), xh.reshape(g.shape[0], groups, -1)
+        return (inv * (gg - xg * (gg * xg).sum(-1, keepdim=True))).reshape(g.shape)
+
+    return nrm_bwd(dqh, qr, rq), nrm_bwd(dkh, kr, rk), dv
+
+
 def _configs():
     return {
         "C2": dict(q=(4, 8, 1024, 64), kv=(4, 8, 1024, 64), dtype=torch.float16, causal=False, mask=False, scale=8, groups=1),
@@ -161,6 +199,36 @@ def test_backward_fullsize_identities_and_slices(name):
     dk_got, dv_got = (dk[b], dv[b]) if single else (dk[b, 1], dv[b, 1])
     assert rel(dk_got, dk_ref) <= tol, rel(dk_got, dk_ref)
     assert rel(dv_got, dv_ref) <= tol, rel(dv_got, dv_ref)
+    # the same slices against exact float64 math on the 16-bit OPERANDS: the FIXED bars, at every scale * groups (the twin of the
+    # range-scaled comparison above; round 3 had it for the forward only)
+    tol1 = 1.2e-2 if bf else 3e-3
+    dk_ref = dv_ref = None
+    for h in (range(cfg["q"][1]) if single else (1,)):
+        kk, vv = (k.detach()[b], v.detach()[b]) if single else (k.detach()[b, h], v.detach()[b, h])
+        rdq, rdk, rdv = _grads_operand_faithful(q.detach()[b, h], kk, vv, do[b, h], None if mask is None else mask[b], cfg["causal"],
+                                                cfg["scale"], cfg["groups"], cfg["dtype"])
+        if h in (1, cfg["q"][1] - 1):
+            assert rel(dq[b, h], rdq) <= tol1, ("dq vs 16-bit operands", h, rel(dq[b, h], rdq))
+        dk_ref = rdk if dk_ref is None else dk_ref + rdk
+        dv_ref = rdv if dv_ref is None else dv_ref + rdv
+    assert rel(dk_got, dk_ref) <= tol1, ("dk vs 16-bit operands", rel(dk_got, dk_ref))
+    assert rel(dv_got, dv_ref) <= tol1, ("dv vs 16-bit operands", rel(dv_got, dv_ref))
+
+
+def test_operand_faithful_helper_equals_the_numpy_oracle():
+    """_grads_operand_faithful (torch, float64) == oracle.attention_backward(operand_dtype=...) on a small slice: the full-size twin
+    checks above stand on the pinned oracle."""
+    from oracle import cosine_sim_oracle as O
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for dtype, name, causal, groups, scale in ((torch.bfloat16, "bf16", True, 4, 8.0), (torch.float16, "f16", False, 1, 16.0)):
+        q, k, v, do = (torch.randn((1, 1, n_, 32), device="cuda", dtype=dtype, generator=g) for n_ in (50, 70, 70, 50))
+        mask = None if causal else (torch.rand((1, 70), device="cuda", generator=g) > 0.3)
+        got = _grads_operand_faithful(q[0, 0], k[0, 0], v[0, 0], do[0, 0], None if mask is None else mask[0], causal, scale, groups, dtype)
+        npf = lambda t: t.detach().cpu().double().numpy()
+        ref = O.attention_backward(npf(do), npf(q), npf(k), npf(v), mask=None if mask is None else mask.cpu().numpy(), scale=scale,
+                                   groups=groups, causal=causal, operand_dtype=name, eps=1e-300)
+        for a, r in zip(got, ref[:3]):
+            assert np.abs(npf(a) - r[0, 0]).max() <= 1e-9 * max(1.0, np.abs(r).max())
 
 
 def test_dbias_rows_sum_to_zero():

@@ -9,6 +9,12 @@ times max(1, scale * groups / 16) for the 16-bit types: the logits are scale * s
 (bf16) / 2^-12 (f16) rounding of the normalised q, k -- which the reference rounds too -- so the error of P grows with
 scale * groups (first fuzz run: bf16 gradients at 1.3-1.7e-2 for scale * groups >= 32 against the 1.2e-2 stated for 8).
 This file is also what found the f16 exponent-window defect fixed by the dynamic-shift forward path.
+
+Round 4: every 16-bit configuration is ALSO compared against exact arithmetic on the 16-bit operands of the S product (oracle
+`operand_dtype`: c1 * q^ and k^ rounded like every 16-bit implementation rounds them, the reference included) with the FIXED
+tolerances -- forward and gradients -- so no bar in this file is wider than the stated one without that range-independent twin.
+NAMED_CASES holds the configuration class of the three exceedances the exploratory fuzzing of round 3 found (scale * groups = 64
+with a handful of rows or l2norm groups of two features): against the operand-faithful reference they sit inside the fixed bars.
 """
 import os
 
@@ -16,6 +22,7 @@ import numpy as np
 import pytest
 import torch
 
+import cases as C
 from oracle import cosine_sim_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -83,8 +90,9 @@ def _npf(t):
     return t.detach().cpu().double().numpy()
 
 
-def evaluate(cfg):
-    """runs one configuration; yields (what, measured, limit) for the forward and every gradient (tools/fuzz_case.py prints them)"""
+def evaluate(cfg, raw=True):
+    """runs one configuration; yields (what, measured, limit) for the forward and every gradient (tools/fuzz_case.py prints them).
+    raw = False: only the operand-faithful comparison (NAMED_CASES)"""
     import flash_cosine_sim_attention_amd as F
     dt = DT[cfg["dtype"]]
     B, H, N, M, D = cfg["B"], cfg["H"], cfg["N"], cfg["M"], cfg["D"]
@@ -120,7 +128,7 @@ def evaluate(cfg):
     # plain_cosine_sim_attention; the reference KERNEL's clamp max(l, 1e-10), taken in exp(S - scale) units, attenuates or
     # zeroes rows at such logit ranges (scale 70: every row).  The oracle restates that clamp, so switch it off there.
     bound = cfg["scale"] * cfg["groups"]
-    dyn = cfg["l2norm"] and ((bound > 11 or cfg["bias"]) if cfg["dtype"] == "f16" else bound > 75)      # fcsa_capi.hip dynamic_shift
+    dyn = C.dynamic_shift_regime(cfg["dtype"], cfg["scale"], cfg["groups"], cfg["l2norm"], cfg["bias"])      # fcsa_capi.hip dynamic_shift
     eps = 1e-300 if dyn else 1e-10
     atol, rtol = FWD_TOL[cfg["dtype"]]
     cond = max(1.0, cfg["scale"] * cfg["groups"] / 16.0) if cfg["dtype"] != "f32" and cfg["l2norm"] else 1.0
@@ -136,15 +144,25 @@ def evaluate(cfg):
         vq = _npf(v)[sl_k] if not cfg["single_kv"] else _npf(v)
         okw = dict(mask=mk, attn_bias=bs, scale=cfg["scale"], groups=cfg["groups"], causal=cfg["causal"], l2norm_qk=cfg["l2norm"],
                    attn_bias_batch_dim=kw["attn_bias_batch_dim"], eps=eps)
-        ro, _ = O.attention_forward_stats(_npf(q)[sl_q], kq, vq, **okw)
         got = _npf(o)[sl_q]
         vmax = max(np.abs(vq).max(), 1e-6)
-        excess = (np.abs(got - ro) - rtol * np.abs(ro)).max()
-        yield f"{pr}: forward excess", excess, cond * atol * max(vmax, 1.0)
-        grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, **okw)
         names = ["dq", "dk", "dv"] + (["d_bias"] if bias is not None else [])
         gots = [_npf(q.grad)[sl_q], _npf(k.grad)[sl_k] if not cfg["single_kv"] else _npf(k.grad),
                 _npf(v.grad)[sl_k] if not cfg["single_kv"] else _npf(v.grad)] + ([_npf(bias.grad)] if bias is not None else [])
+        if cfg["dtype"] != "f32":
+            # operand-faithful twin: exact arithmetic on the 16-bit operands, FIXED bars at every logit range
+            ro, _ = O.attention_forward_stats(_npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], **okw)
+            yield f"{pr}: forward excess (16-bit operands)", (np.abs(got - ro) - rtol * np.abs(ro)).max(), atol * max(vmax, 1.0)
+            grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], **okw)
+            for name, gg, rr in zip(names, gots, grads):
+                rel = np.linalg.norm(gg - rr) / max(np.linalg.norm(rr), 1e-3 * np.sqrt(rr.size))
+                yield f"{pr}: {name} rel-L2 (16-bit operands)", rel, GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
+        if not raw:
+            continue
+        ro, _ = O.attention_forward_stats(_npf(q)[sl_q], kq, vq, **okw)
+        excess = (np.abs(got - ro) - rtol * np.abs(ro)).max()
+        yield f"{pr}: forward excess", excess, cond * atol * max(vmax, 1.0)
+        grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, **okw)
         for name, gg, rr in zip(names, gots, grads):
             # the floor keeps the ratio meaningful when the exact gradient is (nearly) zero.  f32 additionally gets an ABSOLUTE
             # allowance: where P == 1 (N = M = 1, or one unmasked key) dS == P (dP - delta) == 0 exactly and the kernel returns the f32
@@ -163,4 +181,36 @@ def evaluate(cfg):
 @pytest.mark.parametrize("cfg", _configs() + _configs_long(), ids=lambda c: c["id"])
 def test_random_config_matches_oracle(cfg):
     for what, got, lim in evaluate(cfg):
+        assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"
+
+
+def _named(id, **kw):
+    base = dict(id=id, dtype="bf16", B=1, H=2, N=5, M=5, D=16, causal=False, mask=False, bias=False, bias_batch=False, single_kv=False,
+                groups=8, l2norm=True, scale=8.0, seed=1)
+    base.update(kw)
+    return base
+
+
+# The configuration class of round 3's three exploratory exceedances: scale * groups = 64 with a handful of rows
+# or l2norm groups of two features.  Against exact math on the raw inputs bf16 dk measured 7.9e-2 (bar 4.8e-2), f16 dq 1.6e-2 and
+# 3.0e-2 (bar 1.2e-2): the rounding of q^, k^ at that logit range, which the range factor underestimates for tiny problems.  The
+# operand-faithful reference removes exactly that term, so here the FIXED bars apply.  (Also in the list: negative scales, the
+# 60 < scale * groups <= 75 static window, ranges beyond 87, and a long-N short-M masked problem with groups > 1 -- round 3 review.)
+NAMED_CASES = [
+    _named("X1_bf16_g8_s8_d16_n5", seed=101),
+    _named("X2_f16_g8_s8_d16_n5_causal", dtype="f16", causal=True, N=7, M=9, seed=102),
+    _named("X3_f16_g8_s8_d16_n33", dtype="f16", N=33, M=5, seed=103),
+    _named("X4_bf16_g8_s8_d16_single_kv", N=31, M=33, single_kv=True, H=3, seed=104),
+    _named("X5_bf16_negative_scale", groups=1, scale=-8.0, D=64, N=100, M=129, causal=True, seed=105),
+    _named("X6_f16_negative_scale_mask", dtype="f16", groups=2, scale=-4.0, D=32, N=64, M=100, mask=True, seed=106),
+    _named("X7_bf16_bound70_static_window", groups=8, scale=8.75, D=64, N=129, M=129, causal=True, seed=107),
+    _named("X8_bf16_bound70_bias_takes_online", groups=8, scale=8.75, D=64, N=100, M=140, bias=True, seed=108),
+    _named("X9_bf16_bound96_online", groups=8, scale=12.0, D=128, N=257, M=257, causal=True, seed=109),
+    _named("X10_bf16_long_n_short_m_groups_mask", B=1, H=2, groups=2, scale=8.0, D=64, N=2500, M=200, mask=True, seed=110),
+]
+
+
+@pytest.mark.parametrize("cfg", NAMED_CASES, ids=lambda c: c["id"])
+def test_named_case_operand_faithful(cfg):
+    for what, got, lim in evaluate(cfg, raw=False):
         assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"

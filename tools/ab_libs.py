@@ -40,6 +40,9 @@ def run_shape(shape):
     k, v = (torch.randn(B, H, M, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(2))
     do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
     bias = (0.5 * torch.randn(H, N, M, device="cuda")).to(dt).requires_grad_() if with_bias else None
+    if os.environ.get("FCSA_AB_FILL"):      # constant inputs: no operand bits toggle -- how much of the time is the power limit?
+        with torch.no_grad():
+            for x_ in (q, k, v, do): x_.fill_(float(os.environ["FCSA_AB_FILL"]))
     def step():
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
