@@ -151,6 +151,55 @@ def run_extra_config(F, c, sdpa=True):
     return r
 
 
+def accuracy_report(F, w, q, k, v, do, slices):
+    """The metric's second half.  Forward and gradients of the HIP op on (batch, head) slices of the headline workload against a
+    float64 evaluation of the same function of the same bf16 inputs (plain softmax form + torch.autograd, exact l2norm), beside
+    the reference-style PyTorch composite (plain_cosine_sim_attention, py:75-126) evaluated in the SAME dtype on the same slices --
+    the comparator for north_star's "within 1e-3 rel." -- and the HIP op against float64 math on the 16-bit OPERANDS of the S
+    product (c1 * q^, k^ rounded to bf16: the rounding every bf16 implementation shares)."""
+    def stats(got, ref):
+        d = got.double() - ref.double()
+        return {"rel_l2": float(d.norm() / ref.double().norm()), "max_abs": float(d.abs().max())}
+
+    def exact(qs, ks, vs, dos, operand_dtype=None):
+        qs, ks, vs = (t.double().requires_grad_() for t in (qs, ks, vs))
+        qn, kn = torch.nn.functional.normalize(qs, dim=-1), torch.nn.functional.normalize(ks, dim=-1)
+        if operand_dtype is not None:      # straight-through rounding of the operands (the cast's gradient is the identity)
+            c1 = w["scale"] * 1.4426950408889634
+            qn, kn = (qn * c1).to(operand_dtype).double() / c1, kn.to(operand_dtype).double()
+        sc = (qn @ kn.t()) * w["scale"]
+        sc = sc.masked_fill(torch.ones_like(sc, dtype=torch.bool).triu(1), float("-inf"))
+        o = torch.softmax(sc, -1) @ vs
+        (o * dos.double()).sum().backward()
+        return o.detach(), qs.grad, ks.grad, vs.grad
+
+    q.grad = k.grad = v.grad = None
+    o = F.flash_cosine_sim_attention(q, k, v, causal=w["causal"], scale=w["scale"], groups=w["groups"])
+    o.backward(do)
+    names = ("o", "dq", "dk", "dv")
+    acc = {n: {"hip": [], "torch_same_dtype": [], "hip_vs_16bit_operands": []} for n in names}
+    for (b, h) in slices:
+        sl = lambda t: t.detach()[b, h]
+        ref = exact(sl(q), sl(k), sl(v), sl(do))
+        ref16 = exact(sl(q), sl(k), sl(v), sl(do), operand_dtype=q.dtype)
+        got = (sl(o), q.grad[b, h], k.grad[b, h], v.grad[b, h])
+        qc, kc, vc = (t.detach()[b:b + 1, h:h + 1].clone().requires_grad_() for t in (q, k, v))
+        oc = F.plain_cosine_sim_attention(qc, kc, vc, causal=w["causal"], scale=w["scale"], groups=w["groups"])
+        oc.backward(do[b:b + 1, h:h + 1])
+        comp = (oc.detach()[0, 0], qc.grad[0, 0], kc.grad[0, 0], vc.grad[0, 0])
+        for n, g_, c_, r_, r16 in zip(names, got, comp, ref, ref16):
+            acc[n]["hip"].append(stats(g_, r_))
+            acc[n]["torch_same_dtype"].append(stats(c_, r_))
+            acc[n]["hip_vs_16bit_operands"].append(stats(g_, r16))
+    worst = lambda lst: {k_: float("%.3e" % max(x[k_] for x in lst)) for k_ in ("rel_l2", "max_abs")}
+    out = {leg: {n: worst(acc[n][leg]) for n in names} for leg in ("hip", "torch_same_dtype", "hip_vs_16bit_operands")}
+    out["slices"] = [list(s_) for s_ in slices]
+    out["what"] = ("worst over the slices; hip / torch_same_dtype: against float64 softmax(scale * l2norm(q) l2norm(k)^T) v + autograd on the "
+                   "same bf16 inputs and dO (torch_same_dtype = plain_cosine_sim_attention composite in bf16); hip_vs_16bit_operands: against "
+                   "float64 math on c1 * q^, k^ rounded to bf16")
+    return out
+
+
 def reference_protocol(F, w, dt):
     """The reference's timing protocol on the headline workload (flash_cosine_sim_attention/benchmark.py:7-56, 46-48):
     10 warm-ups, mean of 20 calls, each timed by its own device-event pair around `out = fn(); out.sum().backward()`."""
@@ -339,6 +388,13 @@ def main():
                 md = max(md, (o[b, h].float() - ref).abs().max().item())
             max_delta = md
 
+    accuracy = None
+    if rank == 0:
+        try:
+            accuracy = accuracy_report(F, w, q, k, v, do, ((0, 0), (w["B"] - 1, w["H"] - 1)))
+        except Exception as ex:                                   # pragma: no cover
+            accuracy = {"error": repr(ex)[:200]}
+
     # ---- the other configs, the reference's timing protocol, host-bound sizes (rank 0; ~2 s) -----------------------------
     configs = ref_proto = small = None
     if rank == 0 and world == 1 and not args.no_extra_configs:      # (N > 1 runs report the headline only: the other ranks are waiting)
@@ -382,6 +438,7 @@ def main():
                        "flop_convention": "GEMM only: fwd 4*BHNMD + bwd 10*BHNMD, x causal fraction 4097/8192",
                        "algorithmic_gflop_per_step_per_gpu": round(flops(w) / 1e9, 2)},
             "max_abs_delta_vs_pytorch_f32": max_delta,
+            "accuracy": accuracy,
             "roofline": roofline,
             "vs_flash_sdpa": (round(sdpa["ms_per_step"] / ms_per_step, 3) if sdpa and "ms_per_step" in sdpa else None),
             "flash_sdpa": sdpa,

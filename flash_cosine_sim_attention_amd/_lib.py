@@ -18,7 +18,12 @@ LIB_PATH = os.environ.get("FCSA_LIB") or os.path.join(_HERE, "libfcsa_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 FCSA_F32, FCSA_F16, FCSA_BF16 = 0, 1, 2
-HEADER = os.path.join(os.path.dirname(_HERE), "include", "fcsa.h")
+# The C-ABI header the struct layouts below are generated from.  It ships INSIDE the package (`include/fcsa.h` next to this file:
+# in the source tree a link to the repository's include/fcsa.h, in a built / installed copy the file itself -- setup.py lists it as
+# package data), so an installed or vendored copy of the package directory imports without the repository around it; the source
+# tree's own header is the fallback.
+_HEADER_CANDIDATES = (os.path.join(_HERE, "include", "fcsa.h"), os.path.join(os.path.dirname(_HERE), "include", "fcsa.h"))
+HEADER = next((h for h in _HEADER_CANDIDATES if os.path.isfile(h)), _HEADER_CANDIDATES[0])
 
 
 # ---- ctypes mirrors of the structs, GENERATED from include/fcsa.h (one source of truth for the layout; the compiled binding

@@ -47,7 +47,9 @@ setup(
     description="Fused cosine-similarity attention for AMD MI355X (gfx950): hand-written HIP kernels behind the "
                 "flash_cosine_sim_attention(q, k, v, ...) API",
     packages=[PKG],
-    package_data={PKG: ["libfcsa_hip.so", "_fcsa_torch.so", "csrc/*", "../include/fcsa.h"]},
+    # include/fcsa.h: the package's own copy of the C-ABI header (`_lib.py` generates its ctypes structs from it at import time);
+    # in the source tree it is a link to the repository's include/fcsa.h, the build copies the file
+    package_data={PKG: ["libfcsa_hip.so", "_fcsa_torch.so", "csrc/*", "include/fcsa.h"]},
     python_requires=">=3.9",
     install_requires=["torch>=2.4"],
     cmdclass=cmdclass,

@@ -243,3 +243,21 @@ def test_plain_torch_restatement_matches_oracle_on_cpu():
                                          **Cs.op_kwargs(case))
         gold = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["o_plain"]
         assert np.abs(o.numpy() - gold).max() <= 2e-5
+
+
+def test_package_carries_its_own_header_and_imports_without_the_repository(tmp_path):
+    """round 3 advisor: `_lib.py` generates its ctypes structs from the C-ABI header at import time, so the header has to travel with
+    the package.  A copy of the package directory alone (links resolved, as a wheel build or a vendored copy makes it) -- no
+    repository-level include/ next to it -- must import, find its header inside itself and report the same ABI."""
+    import shutil, subprocess, sys, filecmp
+    pkg = os.path.join(ROOT, "flash_cosine_sim_attention_amd")
+    assert filecmp.cmp(os.path.join(pkg, "include", "fcsa.h"), os.path.join(ROOT, "include", "fcsa.h"), shallow=False)
+    dst = tmp_path / "site" / "flash_cosine_sim_attention_amd"
+    shutil.copytree(pkg, dst, symlinks=False, ignore=shutil.ignore_patterns("csrc", "__pycache__", "libfcsa_hip_*.so"))
+    assert not (tmp_path / "site" / "include").exists()
+    code = ("import sys; sys.path.insert(0, %r); from flash_cosine_sim_attention_amd import _lib; "
+            "assert _lib.HEADER.startswith(%r), _lib.HEADER; print(_lib.ABI_VERSION)") % (str(tmp_path / "site"), str(dst))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    from flash_cosine_sim_attention_amd import _lib
+    assert int(out.stdout.strip()) == _lib.ABI_VERSION

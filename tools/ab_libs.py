@@ -20,7 +20,7 @@ binding = ctypes.CDLL(_torch_ops.BINDING_PATH)          # same loaded object as 
 libs, paths = {}, {}
 pkg = os.path.join(ROOT, "flash_cosine_sim_attention_amd")
 def open_lib(path):
-    """ctypes handle with the profile hooks only (older ABI versions are welcome here: the binding falls back for symbols they lack)"""
+    """ctypes handle with the profile hooks only (the binding itself refuses a library of another ABI version: fcsa_torch_use_library -> -3)"""
     lib = ctypes.CDLL(path)
     lib.fcsa_profile_enable.argtypes = [ctypes.c_int32]
     lib.fcsa_profile_collect.argtypes = [ctypes.POINTER(_lib.KernelStat), ctypes.c_int32]
