@@ -34,7 +34,10 @@ def test_cpu_path_matches_reference_fixture(case):
     got = o.double().numpy()
     ok = np.broadcast_to(_valid_rows(case, inp)[..., None], got.shape)
     ref = gold["o_tiled"] if case["tiled_ok"] else gold["o_plain"]     # o_tiled: the reference's own CPU path, where it is usable
-    assert np.abs(np.where(ok, got - ref, 0.0)).max() <= TOL[case["dtype"]]
+    # (`wide` cases: the dtype rounding of q^, k^ -- this path normalises in the input dtype like the reference, py:57-65 -- is
+    #  amplified by the logit range scale * groups; 1 for every other case)
+    cond = C.logit_cond(case["dtype"], case["scale"], case["groups"], case["l2norm"])
+    assert np.abs(np.where(ok, got - ref, 0.0)).max() <= TOL[case["dtype"]] * cond * (1.25 if cond > 1 else 1.0)      # (max-abs over 2e4 values)
     assert np.abs(np.where(ok, 0.0, got)).max() == 0.0                 # rows without a valid key are exactly 0
 
 
