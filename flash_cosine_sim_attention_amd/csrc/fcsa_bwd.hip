@@ -43,8 +43,21 @@ constexpr int kDq2WBytes = 128;      // row bytes D*ES up to which the dQ kernel
 // of what the same kernel reaches at D = 64; smaller grids still do (a lone wave is better off with the pipelined tile).
 template <typename T, int D> constexpr bool dq_can_two_waves() { return D * Traits<T>::ES <= (Traits<T>::ES == 2 ? 256 : 128); }
 constexpr int kDkv2WBytes = 128;     // same for the dKV kernel
-constexpr int kDqSub8 = 4;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
-constexpr int kDkvBmq8 = 128;        // staged query rows of the 8-wave dKV kernel
+#ifndef FCSA_DQ_SUB8
+#define FCSA_DQ_SUB8 4
+#endif
+#ifndef FCSA_DKV_BMQ8
+#define FCSA_DKV_BMQ8 128
+#endif
+#ifndef FCSA_PRIO_BLOCKS
+#define FCSA_PRIO_BLOCKS 0      // 0: half of the interval's blocks
+#endif
+constexpr int kDqSub8 = FCSA_DQ_SUB8;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
+#ifndef FCSA_DQ_SPLIT0
+#define FCSA_DQ_SPLIT0 1
+#endif
+constexpr bool kDqSplitFirstStage = FCSA_DQ_SPLIT0 != 0;      // cold first stage of a dQ pass requested in two parts (bwd_dq_kernel, SPLIT0)
+constexpr int kDkvBmq8 = FCSA_DKV_BMQ8;        // staged query rows of the 8-wave dKV kernel
 constexpr int kDkvBmqWide = 64;      // staged query rows of the dKV kernel for 16-bit D >= 96 (LDS-DMA form)
 #ifndef FCSA_DKV_RING
 #define FCSA_DKV_RING 1
@@ -323,15 +336,29 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
 #pragma unroll
   for (int e = 0; e < RowEpilogue<T, D>::NP; ++e) rinv_n[e] = 1.f;
   bool have_pre = false;
-  auto request_ahead = [&](int b_, int h_, int pass_) {
+  // SPLIT0: a COLD first stage (requested at the top of a pass, nothing to overlap it with: every workgroup of the chip asks for its
+  // 64 KiB stage and its 96 KiB of row chunks at once, ~11 B/clk/CU) is requested in two parts -- the first 64-key tile ahead of the
+  // row chunks, the other tiles of the stage at the top of the first tile, landing while it is computed; one extra barrier behind
+  // that tile publishes them.  Needs piece i of every wave == tile i of the stage.  (A stage requested from inside the previous
+  // pass's epilogue is not split: its flight is covered.)
+  // (not with a bias: its loads inside the tile would be younger than the stage pieces the counted wait must leave in flight)
+  constexpr bool SPLIT0 = DMA && !BIAS && SUB > 1 && DS::PER == SUB && (NW * 1024) / G::ROWB == BN && kDqSplitFirstStage;
+  bool split0 = false;
+  auto request_ahead = [&](int b_, int h_, int pass_, bool cold) {
     int m0_, nt_;
     geometry(pass_, m0_, nt_);
     if constexpr (DMA) {
       stk = dk_.open(p.k.p + (int64_t)b_ * p.k.sb + (int64_t)h_ * p.k.sh + (int64_t)k_lo * p.k.sn, p.k.sn, Mk);
       stv = dv_.open(p.v.p + (int64_t)b_ * p.v.sb + (int64_t)h_ * p.v.sh + (int64_t)k_lo * p.v.sn, p.v.sn, Mk);
+      split0 = SPLIT0 && cold && nt_ > 1;
       if (nt_ > 0) {
-        dk_.issue(stk, lds0, wave);
-        dv_.issue(stv, lds0 + HALF_B, wave);
+        if (SPLIT0 && split0) {
+          dk_.issue_piece(stk, lds0, 0, wave);
+          dv_.issue_piece(stv, lds0 + HALF_B, 0, wave);
+        } else {
+          dk_.issue(stk, lds0, wave);
+          dv_.issue(stv, lds0 + HALF_B, wave);
+        }
       }
     }
     if constexpr (!SEP) return;      // (without SEP the rows are loaded where they are used: fewer registers live at once)
@@ -373,7 +400,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
   // (the first stage is requested ahead of the row chunks and the delta reduction -- or, with SEP, before the previous epilogue)
-  if (!have_pre) request_ahead(b, h, pass);
+  if (!have_pre) request_ahead(b, h, pass, true);
 
   // Q, dO fragments (B operands) and delta = <dO_i, O_i>  (replaces backward_preprocess, cu:1256-1335)
   u32x4 qf[G::KS], dof[G::KS];
@@ -484,6 +511,15 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
           mb = key < Mk ? mrow[key] : (uint8_t)0;
         }
       }
+      if constexpr (SPLIT0) {
+        if (split0 && t == 0) {      // the rest of the cold first stage (ahead of stage 1's requests: it is needed first)
+#pragma unroll
+          for (int i = 1; i < DS::PER; ++i) {
+            dk_.issue_piece(stk, lds0, i, wave);
+            dv_.issue_piece(stv, lds0 + HALF_B, i, wave);
+          }
+        }
+      }
       if (sub == 0 && more) {       // the buffer of stage u + 1 was last read in stage u - 1, which ended with a barrier
         if constexpr (DMA) {
           stk.off += k_step;
@@ -518,6 +554,13 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
         dq_tile<T, D, 0, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
       }
       FCSA_STAMP(ts, 2);
+      if constexpr (SPLIT0) {
+        if (split0 && t == 0 && !last_of_stage) {      // publish tiles 1 .. of the first stage (stage 1's pieces -- 2 * PER, younger -- stay in flight)
+          if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DS::PER) : "memory");
+          else dma_wait();
+          __syncthreads();
+        }
+      }
       if (last_of_stage) {                                 // workgroup-uniform
         if (more) {
           if constexpr (DMA) {
@@ -566,7 +609,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     have_pre = false;
     if constexpr (SEP) {
       if (pass + 1 < npass) {
-        request_ahead(b, h, pass + 1);
+        request_ahead(b, h, pass + 1, false);
         have_pre = true;
       }
     }
@@ -799,13 +842,16 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
                        f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
                        const BwdParams& p, uint32_t kmask, uint32_t ncm, int j, int i0, int diff, const char* bias_col, Trace& ts,
                        BiasBlock<T>& bb, char* bscr, const char* bias_blk, bool bvec, int next_i0, int lane, const char* vown = nullptr,
-                       int vrow0 = 0) {
+                       int vrow0 = 0, bool young = false) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
 #pragma unroll
   for (int ib = 0; ib < BMQ / 32; ++ib) {
     if constexpr (LEAN) FCSA_FENCE();      // blocks stay apart: interleaved by the scheduler, two blocks' fragments do not fit 256 registers
+    if constexpr (LEAN && kPrioLean == 1) {      // barrier interval = ONE or two blocks here: the younger half is favoured through the
+      if (BMQ == 32 || ib == 0) { if (young) __builtin_amdgcn_s_setprio(1); }      // first half of it (see kPrioBwd)
+    }
     if constexpr (BIAS) {
       if (bvec) {      // this block's bias values (requested one block ago) -> scratch; request the next block's (see BiasBlock)
         bb.stage(bscr, lane);
@@ -864,6 +910,9 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
     SecondB<T> pp, pd;
     pp.prep(pr);
     pd.prep(s);
+    if constexpr (LEAN && kPrioLean == 1) {
+      if (BMQ == 32) { if (young) __builtin_amdgcn_s_setprio(0); }
+    }
     FCSA_STAMP(ts, 3 + 3 * ib);
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
@@ -871,6 +920,9 @@ FCSA_DEV void dkv_tile(const char* qt, const char* dot, const float* lcs, const 
       dk[db] = second_mma<T, D>(dk[db], qt, 32 * ib, db, pd, fa);
     }
     FCSA_STAMP(ts, 4 + 3 * ib);
+    if constexpr (LEAN && kPrioLean == 1) {
+      if (BMQ == 64 && ib == 0) { if (young) __builtin_amdgcn_s_setprio(0); }
+    }
   }
 }
 
@@ -929,7 +981,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     FCSA_FENCE();
     if constexpr (kPrioBwd == 1) {      // (`young` is wave-uniform and lives in an SGPR: a scalar branch around one s_setprio)
       if (ib == 0) { if (young) __builtin_amdgcn_s_setprio(1); }
-      if (ib == NB / 2) { if (young) __builtin_amdgcn_s_setprio(0); }
+      if (ib == (FCSA_PRIO_BLOCKS ? FCSA_PRIO_BLOCKS : NB / 2)) { if (young) __builtin_amdgcn_s_setprio(0); }
     }
     if (ib == 1) FCSA_STAMP(ts, 2);
     // ---- M1: S = Q K^T + lc, dP = dO V^T - delta (the per-query terms are the accumulators' initial values)
@@ -1316,7 +1368,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
         }
       } else if constexpr (LEAN) {
         if (!skip) dkv_tile<T, D, BMQ, MODE, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
-                                                            bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32);
+                                                            bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32, NW == 8 && wave >= 4);
       } else {
         const int next_i0 = more ? i0 + BMQ : -1;
         if (!skip) {
@@ -1460,12 +1512,13 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
   const dim3 grid((unsigned)((int64_t)p.B * p.H * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1));
   // (two instantiations, see launch_fwd_nw.  The two-wave form of 256-byte rows sits at its 256 registers: its non-causal
   //  instantiation came out with spill reloads inside the tile loops -- +5.6 % time -- so those launches keep the general kernel)
-  if (p.causal || (TWO && D * Traits<T>::ES >= 256)) {
+  constexpr bool GENERAL_ONLY = TWO && D * Traits<T>::ES >= 256;      // (its non-causal twin is not even instantiated)
+  if (p.causal || GENERAL_ONLY) {
     auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, false>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
-  } else {
+  } else if constexpr (!GENERAL_ONLY) {
     auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, true>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;

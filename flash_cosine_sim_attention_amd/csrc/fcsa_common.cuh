@@ -163,6 +163,10 @@ template <typename T> FCSA_DEV f32x16 key_mask_rank1_cols(f32x16 c, bool key_mas
 #ifndef FCSA_PRIO_FWD
 #define FCSA_PRIO_FWD 0
 #endif
+#ifndef FCSA_PRIO_LEAN
+#define FCSA_PRIO_LEAN 0
+#endif
+constexpr int kPrioLean = FCSA_PRIO_LEAN;      // the same idea in the lean (16-bit D = 96 / 128, two waves per SIMD) dK/dV form
 constexpr int kPrioBwd = FCSA_PRIO_BWD;
 constexpr int kPrioFwd = FCSA_PRIO_FWD;
 

@@ -44,7 +44,10 @@
 namespace fcsa {
 // 64-key tiles per LDS stage of fwd_kernel where the stages arrive by LDS-DMA.  One: this kernel's barrier sits in the MIDDLE of a
 // tile (mid()), where the old wave of a SIMD waits less than at a tile end; two per stage measured +1.8 % time at C3.
-constexpr int kFwdSub = 1;
+#ifndef FCSA_FWD_SUB
+#define FCSA_FWD_SUB 1
+#endif
+constexpr int kFwdSub = FCSA_FWD_SUB;
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
 #endif
@@ -730,6 +733,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       const bool last_of_stage = sub == SUB - 1 || t + 1 >= nt;   // workgroup-uniform
       FCSA_STAMP(ts, 0);
       if constexpr (kPrioFwd == 1 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
+      if constexpr (kPrioFwd == 2 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }      // (mirror: favoured from the tile top to the barrier)
       uint64_t word = 0;
       if constexpr (MASKED) {
         // consume the mask byte loaded one tile ago BEFORE issuing new loads (its wait then covers nothing else)
@@ -775,6 +779,12 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
           // (kPrioFwd: the younger half of the workgroup is favoured from the barrier to the end of the tile, the older half -- by age --
           //  from the top of the next tile to the barrier; see fcsa_common.cuh)
           if constexpr (kPrioFwd == 1 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+          if constexpr (kPrioFwd == 2 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
+          if constexpr (kPrioFwd == 3 && NW == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+        } else {
+          if constexpr (kPrioFwd == 3 && NW == 8) {      // (multi-tile stages: the younger half is favoured for the first half of the interval)
+            if (sub == SUB / 2 - 1) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
+          }
         }
         FCSA_STAMP(ts, 6);
       };
