@@ -130,7 +130,11 @@ typedef struct fcsa_forward_args {
 typedef struct fcsa_backward_args {
   fcsa_problem    p;
   fcsa_tensor     d_out, o;      /* [B,H,N,D] */
-  const float*    inv_l;         /* [B,H,N] from forward */
+  const float*    inv_l;         /* [B,H,N] from forward.  Its encoding (1 / rowsum, or log2 of it) is a function of `p`
+                                    AND of whether an attn_bias is present: fcsa_backward must be given the same problem
+                                    and the same bias (NULL or not) as the fcsa_forward call that wrote it -- which the
+                                    mathematics requires anyway (dS depends on the bias) -- and an inv_l is only valid for
+                                    the library version that produced it */
   fcsa_tensor     q, k, v;       /* the same tensors forward saw (q,k ignored when l2norm_qk: qn/kn are used) */
   const uint8_t*  mask;
   const void*     attn_bias;
