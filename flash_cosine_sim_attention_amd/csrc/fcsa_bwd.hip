@@ -1492,365 +1492,6 @@ extern "C" int fcsa_trace_read_dkv(unsigned long long* out) {
 namespace fcsa {
 #endif
 
-// =============================================================================================
-// Slot-scheduled dK / dV kernel for ONE wave per SIMD (16-bit types, no bias, no key mask): 4 waves per workgroup, each owning KB 32-key
-// blocks (KB = 1: rows of 192 .. 256 bytes, D = 96 / 128, where a wave's registers do not allow a partner on its SIMD anyway -- C5's
-// grid, 256 four-wave workgroups, is the case in point; KB = 2 is the 64-keys-per-wave form measured at D = 64 in round 4,
-// profiles/NOTES.md).  With no partner wave to fill its stalls, everything a wave does is software-pipelined against its own MFMAs in
-// fenced issue slots (as fwd2_kernel; hipcc's list scheduler does not keep such an interleave by itself): at D = 128 a 32-query block
-// is 32 MFMAs with 48 VALU instructions and 56 LDS reads, i.e. ~3.3 fillers per MFMA gap (the gap probe: up to ~5 are free).  The
-// per-query seeds are read once per block and enter the chains as the C operand of their first MFMA; the three-buffer LDS-DMA ring
-// makes block 0 of the NEXT tile readable before the tile barrier.  One call = one block b, two groups:
-//
-//     G1  M2(b-1): dV, dK of the previous block (accumulators pinned in AGPRs) | X(b), first half: exp, dS, pack | R(b+1): row fragments + seeds
-//     G2  M1(b+1): S, dP chains of the next block                              | X(b), second half               | T(b): transposed fragments
-//
-// i.e. the exp / dS / pack work of a block is spread over the 32 MFMAs that follow its S / dP chains -- three VALU instructions and one
-// LDS read per MFMA slot -- and every LDS result has a whole group to arrive.  State alternates between two register sets (PAR), so the
-// rotation needs no copies; the three-buffer LDS ring makes block 0 of the NEXT tile readable before the tile barrier.
-// =============================================================================================
-template <typename T, int D, int KB> struct DkvWideState {
-  typedef TileGeom<D, 2> G;
-  u32x4 qa[G::KS], da[G::KS];            // row fragments of block b + 1
-  f32x16 seed_s, seed_p;                 // its per-query terms: log2-normaliser (S chains), -delta (dP chains)
-  f32x16 s[2][KB], dp[2][KB];            // [set][key block]: set PAR = block b (X in flight), set PAR ^ 1 = block b + 1 (M1)
-  u32x4 tq[G::DB][2], td[G::DB][2];      // transposed fragments: of block b - 1 during G1, re-requested for block b in G2
-  SecondB<T> pp[2][KB], pd[2][KB];       // [set][key block] packed P / dS: set PAR = block b - 1 (M2), set PAR ^ 1 = block b (X)
-  // (one set would do for key block 0's logits and key block 1's packed operands -- measured: hipcc then spills 219 registers)
-};
-
-// R: the x-th of 2 * KS + 8 LDS reads that fetch block (tile, rb)'s row fragments and per-query seeds
-template <typename T, int D, int KB>
-FCSA_DEV void dkv_wide_request_one(DkvWideState<T, D, KB>& st, int x, const char* qt, const char* dot, const float* lcs, const float* dls, int rb,
-                                   const FragAddr<T, D>& fa) {
-  typedef TileGeom<D, 2> G;
-  if (x < G::KS) st.qa[x] = fa.row_frag(qt, rb, x);
-  else if (x < 2 * G::KS) st.da[x - G::KS] = fa.row_frag(dot, rb, x - G::KS);
-  else {
-    const int y = x - 2 * G::KS, rq = y & 3;
-    const f32x4 v = *reinterpret_cast<const f32x4*>((y < 4 ? lcs : dls) + rb + 8 * rq + 4 * fa.hi);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) (y < 4 ? st.seed_s : st.seed_p)[4 * rq + e] = v[e];
-  }
-}
-
-// X: one of the 16 steps that turn (s, dp) of one key block into packed P and dS.  Even steps exponentiate a pair of logits, odd
-// steps finish it: dS = P (dP - delta), both packed.
-template <typename T, bool MASKED>
-FCSA_DEV void dkv_wide_x_step(f32x16& s, const f32x16& dp, uint32_t w, SecondB<T>& pp, SecondB<T>& pd, int x) {
-  const int c = x >> 1;
-  if ((x & 1) == 0) {
-    float e0 = fast_exp2(s[2 * c]), e1 = fast_exp2(s[2 * c + 1]);
-    if constexpr (MASKED) {
-      e0 = ((w >> crow(2 * c, 0)) & 1u) ? e0 : 0.f;
-      e1 = ((w >> crow(2 * c + 1, 0)) & 1u) ? e1 : 0.f;
-    }
-    s[2 * c] = e0;
-    s[2 * c + 1] = e1;
-  } else {
-    pp.v[c >> 2][c & 3] = Traits<T>::pack2(s[2 * c], s[2 * c + 1]);
-    pd.v[c >> 2][c & 3] = Traits<T>::pack2(s[2 * c] * dp[2 * c], s[2 * c + 1] * dp[2 * c + 1]);
-  }
-}
-
-// M2: the m-th of 4 * DB * KB accumulate-only MFMAs of a block: dV[kb] += dO^T P[kb], dK[kb] += Q^T dS[kb]
-template <typename T, int D, int KB>
-FCSA_DEV void dkv_wide_m2_one(DkvWideState<T, D, KB>& st, int set, int m, f32x16 (&dk)[KB][TileGeom<D, 2>::DB], f32x16 (&dv)[KB][TileGeom<D, 2>::DB]) {
-  typedef TileGeom<D, 2> G;
-  const int ks = m / (2 * G::DB * KB), r = m % (2 * G::DB * KB), db = r / (2 * KB), kb = (r % (2 * KB)) >> 1;
-  if ((r & 1) == 0) Traits<T>::mfma32_agpr(st.td[db][ks], st.pp[set][kb].v[ks], dv[kb][db]);
-  else Traits<T>::mfma32_agpr(st.tq[db][ks], st.pd[set][kb].v[ks], dk[kb][db]);
-}
-
-// one block; (qn, don, lcn, dln, rbn) = block b + 1 (this tile, or block 0 of the next tile), (qc, doc, rbc) = block b
-template <typename T, int D, int KB, bool MASKED, int PAR>
-FCSA_DEV void dkv_wide_block(DkvWideState<T, D, KB>& st, const char* qn, const char* don, const float* lcn, const float* dln, int rbn,
-                             const char* qc, const char* doc, int rbc, const FragAddr<T, D>& fa,
-                             const u32x4 (&kf)[KB][TileGeom<D, 2>::KS], const u32x4 (&vf)[KB][TileGeom<D, 2>::KS],
-                             f32x16 (&dk)[KB][TileGeom<D, 2>::DB], f32x16 (&dv)[KB][TileGeom<D, 2>::DB], const uint32_t (&w)[KB]) {
-  typedef TileGeom<D, 2> G;
-  typedef Traits<T> TR;
-  constexpr int NM2 = 4 * G::DB * KB, NM1 = 2 * G::KS * KB, NR = 2 * G::KS + 8, NT = 4 * G::DB, NX = 16 * KB;
-  // X step y of the block: key block y / 16, step y % 16 (dkv_wide_x_step); steps [0, NX / 2) ride in G1, the rest in G2
-  auto xstep = [&](int y) {
-    const int kb = y >> 4;
-    dkv_wide_x_step<T, MASKED>(st.s[PAR][kb], st.dp[PAR][kb], w[kb], st.pp[PAR ^ 1][kb], st.pd[PAR ^ 1][kb], y & 15);
-  };
-  FCSA_FENCE();
-  // ---- G1
-#pragma unroll
-  for (int m = 0; m < NM2; ++m) {
-    dkv_wide_m2_one<T, D, KB>(st, PAR, m, dk, dv);
-    FCSA_SHARE(m, NM2, NR, x) dkv_wide_request_one<T, D, KB>(st, x, qn, don, lcn, dln, rbn, fa);
-    FCSA_SHARE(m, NM2, NX / 2, y) xstep(y);
-    FCSA_FENCE();
-  }
-  // ---- G2
-#pragma unroll
-  for (int m = 0; m < NM1; ++m) {
-    const int kk = m / (2 * KB), ch = m % (2 * KB), kb = ch % KB;
-    if (ch < KB) st.s[PAR ^ 1][kb] = TR::mfma32(st.qa[kk], kf[kb][kk], kk == 0 ? st.seed_s : st.s[PAR ^ 1][kb]);
-    else st.dp[PAR ^ 1][kb] = TR::mfma32(st.da[kk], vf[kb][kk], kk == 0 ? st.seed_p : st.dp[PAR ^ 1][kb]);
-    FCSA_SHARE(m, NM1, NT, x) {
-      const int db = x >> 2, h = (x >> 1) & 1;
-      if ((x & 1) == 0) st.td[db][h] = fa.tr_frag(doc, rbc + 16 * h, db);
-      else st.tq[db][h] = fa.tr_frag(qc, rbc + 16 * h, db);
-    }
-    FCSA_SHARE(m, NM1, NX / 2, y) xstep(NX / 2 + y);
-    FCSA_FENCE();
-  }
-}
-
-template <typename T, int D, int KB, int BMQ, bool KM>      // KM: not causal (no key mask either: those launches keep the other kernels)
-__global__ void __launch_bounds__(256, 1) bwd_dkv_slot_kernel(const BwdParams p) {
-  const int causal = KM ? 0 : p.causal;
-  typedef TileGeom<D, 2> G;
-  typedef Traits<T> TR;
-  static_assert(TR::ES == 2 && (BMQ == 64 || BMQ == 128), "slot-scheduled dK/dV: 16-bit types, two or four blocks per tile");
-  constexpr int NW = 4, KW = 32 * KB, BNK = KW * NW, NB = BMQ / 32;
-  constexpr int TILE_B = BMQ * G::ROWB, BUF_B = 2 * TILE_B + 2 * BMQ * 4;      // Q tile | dO tile | lc[BMQ] | -delta[BMQ]
-  typedef DkvLds<T, D, NW, BMQ, false, false, 3> LDS;
-  static_assert(!LDS::SEP, "ring form: the epilogue scratch lies inside the staging buffers");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][BUF_B]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  FragAddr<T, D> fa;
-  fa.init(lane);
-  const int KT = (p.M + BNK - 1) / BNK;
-  const int PT = causal ? (KT + 1) / 2 : KT;
-  int bh, pt;
-  block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
-  const int b = bh / p.H, h = bh % p.H;
-  const int npass = (causal && (KT - 1 - pt) != pt) ? 2 : 1;
-  const int diff = p.M - p.N;
-  const int QT = (p.N + BMQ - 1) / BMQ;
-  const uint32_t ncm = causal ? 0u : 0xffffffffu;
-  const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
-  const char* dobase = p.d_out.p + (int64_t)b * p.d_out.sb + (int64_t)h * p.d_out.sh;
-  const float* invl_row = p.inv_l + ((int64_t)b * p.H + h) * p.N;
-  const float* delta_row = p.delta + ((int64_t)b * p.H + h) * p.N;
-  typedef DmaStager<T, D, BMQ, NW> DS;
-  DS dq_, ddo_;
-  dq_.init(p.q.sn, wave, lane);
-  ddo_.init(p.d_out.sn, wave, lane);
-  typename DS::Stream stq, stdo;
-  const uint32_t q_step = (uint32_t)(BMQ * p.q.sn), do_step = (uint32_t)(BMQ * p.d_out.sn), lds0 = DS::lds_addr(smem);
-  const bool far = BMQ * p.q.sn > (int64_t)DS::REBASE || BMQ * p.d_out.sn > (int64_t)DS::REBASE;
-  auto advance = [&](int t) {
-    stq.off += q_step;
-    stdo.off += do_step;
-    if (far || (stq.off | stdo.off) > DS::REBASE) {
-      stq = dq_.open(qbase + (int64_t)t * BMQ * p.q.sn, p.q.sn, p.N - t * BMQ);
-      stdo = ddo_.open(dobase + (int64_t)t * BMQ * p.d_out.sn, p.d_out.sn, p.N - t * BMQ);
-    }
-  };
-  auto issue_tile = [&](int buf) {
-    dq_.issue(stq, lds0 + buf * BUF_B, wave);
-    ddo_.issue(stdo, lds0 + buf * BUF_B + TILE_B, wave);
-  };
-  // per-query terms of a tile: raw loads into (lc, dl, ok), written to the tile's buffer behind the DMA wait
-  auto load_terms = [&](int t, float& lc, float& dl, bool& ok) {
-    if (tid < BMQ) {
-      const int i = min(t * BMQ + tid, p.N - 1);
-      lc = invl_row[i];
-      dl = delta_row[i];
-      ok = t * BMQ + tid < p.N;
-    }
-  };
-  auto store_terms = [&](char* buf, float lc, float dl, bool ok) {
-    if (tid < BMQ) {
-      reinterpret_cast<float*>(buf + 2 * TILE_B)[tid] = ok ? (p.invl_log2 ? lc : __builtin_amdgcn_logf(lc)) - p.c2 : -INFINITY;      // rows >= N: P = 0
-      reinterpret_cast<float*>(buf + 2 * TILE_B + BMQ * 4)[tid] = ok ? -dl : 0.f;
-    }
-  };
-
-  for (int pass = 0; pass < npass; ++pass) {
-    const int kt = causal ? (pass == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
-    const int n0 = kt * BNK, nw = n0 + wave * KW;
-    const int t0 = causal ? max(0, n0 - diff) / BMQ : 0;
-    // first two tiles of the pass -> buffers 0, 1
-    float lc_a = 0.f, dl_a = 0.f, lc_b = 0.f, dl_b = 0.f;
-    bool ok_a = false, ok_b = false;
-    stq = dq_.open(qbase + (int64_t)t0 * BMQ * p.q.sn, p.q.sn, p.N - t0 * BMQ);
-    stdo = ddo_.open(dobase + (int64_t)t0 * BMQ * p.d_out.sn, p.d_out.sn, p.N - t0 * BMQ);
-    if (t0 < QT) { issue_tile(0); load_terms(t0, lc_a, dl_a, ok_a); }
-    if (t0 + 1 < QT) { advance(t0 + 1); issue_tile(1); load_terms(t0 + 1, lc_b, dl_b, ok_b); }
-    // K, V fragments of this lane's two keys (B operands of S = Q K^T and dP = dO V^T), kept for the whole pass
-    u32x4 kf[KB][G::KS], vf[KB][G::KS];
-    uint32_t kmask[KB];
-    int jk[KB];
-    {
-      const int ln = opaque(lane), hi_ = ln >> 5;
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const int j = nw + 32 * kb + (ln & 31);
-        jk[kb] = j;
-        const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j * p.k.sn;
-        const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j * p.v.sn;
-#pragma unroll
-        for (int kk = 0; kk < G::KS; ++kk) {
-          const u32x4 z = {0u, 0u, 0u, 0u};
-          kf[kb][kk] = z;
-          vf[kb][kk] = z;
-          if (j < p.M) {
-            kf[kb][kk] = *reinterpret_cast<const u32x4*>(krow + (2 * kk + hi_) * 16);
-            if (!p.q_scaled) kf[kb][kk] = scale_frag<T>(kf[kb][kk], p.c1);
-            vf[kb][kk] = *reinterpret_cast<const u32x4*>(vrow + (2 * kk + hi_) * 16);
-          }
-        }
-        kmask[kb] = j < p.M ? 0xffffffffu : 0u;
-      }
-    }
-    f32x16 dk[KB][G::DB], dv[KB][G::DB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[kb][db][r] = 0.f; dv[kb][db][r] = 0.f; }
-    dma_wait();
-    if (t0 < QT) store_terms(smem, lc_a, dl_a, ok_a);
-    if (t0 + 1 < QT) store_terms(smem + BUF_B, lc_b, dl_b, ok_b);
-    __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // every prologue load is complete on ALL paths (see bwd_dkv_kernel)
-
-    // tiles [t0, t_m) need masking for THIS wave (invalid keys: all of them; causal: those that touch the diagonal), [t_m, QT) do not
-    int t_m = QT;
-    if (n0 + BNK <= p.M) {
-      t_m = t0;
-      if (causal) t_m = min(QT, max(t0, (nw + KW - 1 - diff + BMQ - 1) / BMQ));
-    }
-    DkvWideState<T, D, KB> st;
-    bool started = false;      // wave-uniform: the pipeline holds a block
-    int ring = 0;
-    auto run = [&](auto masked_tag, int t_begin, int t_end) {
-      constexpr bool MASKED = decltype(masked_tag)::value;
-      for (int t = t_begin; t < t_end; ++t) {
-        const int i0 = t * BMQ;
-        const int par_nxt = ring == 2 ? 0 : ring + 1, par_ld = ring == 0 ? 2 : ring - 1;
-        const char* cur = smem + ring * BUF_B;
-        const bool more = t + 2 < QT;
-        float lc_n = 0.f, dl_n = 0.f;
-        bool ok_n = false;
-        if (more) {
-          advance(t + 2);
-          load_terms(t + 2, lc_n, dl_n, ok_n);
-          issue_tile(par_ld);
-        }
-        bool skip = false;
-        if constexpr (MASKED) skip = causal && !started && (i0 + BMQ - 1 + diff < nw);      // no valid pair for this wave yet
-        if (!skip) {
-          const float* lcs = reinterpret_cast<const float*>(cur + 2 * TILE_B);
-          if (!started) {
-            // pipeline start: block 0 of this tile through R + M1 alone; nothing to accumulate for "block -1"
-#pragma unroll
-            for (int x = 0; x < 2 * G::KS + 8; ++x) dkv_wide_request_one<T, D, KB>(st, x, cur, cur + TILE_B, lcs, lcs + BMQ, 0, fa);
-#pragma unroll
-            for (int kk = 0; kk < G::KS; ++kk)
-#pragma unroll
-              for (int kb = 0; kb < KB; ++kb) {
-                st.s[0][kb] = TR::mfma32(st.qa[kk], kf[kb][kk], kk == 0 ? st.seed_s : st.s[0][kb]);
-                st.dp[0][kb] = TR::mfma32(st.da[kk], vf[kb][kk], kk == 0 ? st.seed_p : st.dp[0][kb]);
-              }
-            const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) { st.pp[0][kb].v[0] = z; st.pp[0][kb].v[1] = z; st.pd[0][kb].v[0] = z; st.pd[0][kb].v[1] = z; }
-#pragma unroll
-            for (int db = 0; db < G::DB; ++db) { st.tq[db][0] = z; st.tq[db][1] = z; st.td[db][0] = z; st.td[db][1] = z; }
-            started = true;
-          }
-          const bool has_next = t + 1 < QT;
-          const char* nxt = has_next ? smem + par_nxt * BUF_B : cur;      // (no next tile: the requests read this one again and are never used)
-          const float* lcn = reinterpret_cast<const float*>(nxt + 2 * TILE_B);
-          uint32_t w[NB][KB];
-#pragma unroll
-          for (int ib = 0; ib < NB; ++ib)
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-              w[ib][kb] = MASKED ? (kmask[kb] & (ge_mask(jk[kb] - diff - (i0 + 32 * ib + 4 * fa.hi)) | ncm)) : 0xffffffffu;
-          // blocks of this tile (parities 0, 1, 0, 1); the last one requests and starts block 0 of the NEXT tile
-          if constexpr (NB == 4) {
-            dkv_wide_block<T, D, KB, MASKED, 0>(st, cur, cur + TILE_B, lcs, lcs + BMQ, 32, cur, cur + TILE_B, 0, fa, kf, vf, dk, dv, w[0]);
-            dkv_wide_block<T, D, KB, MASKED, 1>(st, cur, cur + TILE_B, lcs, lcs + BMQ, 64, cur, cur + TILE_B, 32, fa, kf, vf, dk, dv, w[1]);
-          }
-          dkv_wide_block<T, D, KB, MASKED, 0>(st, cur, cur + TILE_B, lcs, lcs + BMQ, BMQ - 32, cur, cur + TILE_B, BMQ - 64, fa, kf, vf, dk, dv, w[NB - 2]);
-          dkv_wide_block<T, D, KB, MASKED, 1>(st, nxt, nxt + TILE_B, lcn, lcn + BMQ, 0, cur, cur + TILE_B, BMQ - 32, fa, kf, vf, dk, dv, w[NB - 1]);
-        }
-        if (more) {
-          dma_wait();
-          store_terms(smem + par_ld * BUF_B, lc_n, dl_n, ok_n);
-        }
-        __syncthreads();
-        ring = par_nxt;
-      }
-    };
-    run(std::true_type{}, t0, t_m);
-    run(std::false_type{}, t_m, QT);
-    if (started) {      // drain: dV, dK of the last block (its packed operands are set 0 again after an even number of blocks)
-#pragma unroll
-      for (int m = 0; m < 4 * G::DB * KB; ++m) dkv_wide_m2_one<T, D, KB>(st, 0, m, dk, dv);
-    }
-    mfma_drain();
-
-    // epilogue through the LDS (RowEpilogue), one 32-key block at a time; every tile ended with a barrier: the staging buffers are free
-    {
-      typedef RowEpilogue<T, D> EP;
-      char* scr = LDS::scratch(smem, wave);
-      char* xs = LDS::xarea(smem, wave);
-      const bool fused = p.rk != nullptr;
-      const int le = opaque(lane);
-      const float kmul = p.q_scaled ? p.scale / p.c1 : p.scale;
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const int nwk = nw + 32 * kb, rows_valid = p.M - nwk;
-        float rinv[EP::NP];
-#pragma unroll
-        for (int e = 0; e < EP::NP; ++e) rinv[e] = 1.f;
-        if (fused && rows_valid > 0) EP::load_inv(rinv, p.rk + (((int64_t)b * p.H + h) * p.M + nwk) * p.G, p.G, p.lgm, le, rows_valid);
-        if (rows_valid > 0) {
-          char* dk0 = p.dk.p + (int64_t)b * p.dk.sb + (int64_t)h * p.dk.sh + (int64_t)nwk * p.dk.sn;
-          char* dv0 = p.dv.p + (int64_t)b * p.dv.sb + (int64_t)h * p.dv.sh + (int64_t)nwk * p.dv.sn;
-          const char* x0 = fused ? p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)nwk * p.k.sn : nullptr;
-          u32x4 xf[G::KS];      // (a copy: selecting between &kf[0] and &kf[1] through the unrolled loop sent the fragments through scratch)
-#pragma unroll
-          for (int kk = 0; kk < G::KS; ++kk) xf[kk] = kf[kb][kk];
-          EP::put(scr, dk[kb], kmul, le, (LDS::X && fused) ? xf : nullptr, xs, LDS::XPITCH);
-          EP::template finish<LDS::X>(scr, xs, LDS::XPITCH, le, dk0, p.dk.sn, rows_valid, fused ? false : p.dk_f32 != 0, x0, p.k.sn, 1.f, rinv, p.lgm,
-                                      p.norm_eps);
-          EP::put(scr, dv[kb], 1.f, le, nullptr, xs, LDS::XPITCH);
-          EP::template finish<false>(scr, xs, LDS::XPITCH, le, dv0, p.dv.sn, rows_valid, p.dv_f32 != 0, nullptr, 0, 1.f, rinv, 0, 1.f);
-        }
-      }
-      if (pass + 1 < npass) __syncthreads();      // the scratch overlaps the staging buffers of the next pass
-    }
-  }   // pass
-}
-
-#ifndef FCSA_DKV_SLOT
-#define FCSA_DKV_SLOT 1
-#endif
-constexpr bool kDkvSlot = FCSA_DKV_SLOT != 0;      // slot-scheduled one-wave-per-SIMD dK/dV for 16-bit rows of 192 .. 256 bytes
-
-template <typename T, int D>
-static hipError_t launch_dkv_slot(const BwdParams& p, hipStream_t s) {
-  if constexpr (Traits<T>::ES == 2 && D * 2 >= 192 && D * 2 <= 256) {
-    constexpr int KB = 1, BMQ = 64, BNK = 32 * KB * 4;
-    const int KT = (p.M + BNK - 1) / BNK;
-    const int PT = p.causal ? (KT + 1) / 2 : KT;
-    const size_t lds = DkvLds<T, D, 4, BMQ, false, false, 3>::TOTAL;
-    const dim3 grid((unsigned)(p.B * p.H * PT));
-    {      // (ONE instantiation, causal or not at run time: the compile-time non-causal twin came out with spilled registers)
-      auto kern = bwd_dkv_slot_kernel<T, D, KB, BMQ, false>;
-      static std::atomic<uint64_t> lds_ok{0};
-      if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    }
-    return hipGetLastError();
-  }
-  return hipErrorInvalidValue;
-}
-
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
 static int tile_waves(int64_t batch_heads, int len, bool causal) {
@@ -1938,12 +1579,6 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if (p.dkv_splits > 1) return launch_dkv_nw<T, D, BIAS, 4>(p, s);       // split-query path: 128-key tiles x query ranges
-#ifndef FCSA_DKV_SLOT_MODE
-#define FCSA_DKV_SLOT_MODE 2
-#endif
-  if constexpr (kDkvSlot && !BIAS && Traits<T>::ES == 2 && D * Traits<T>::ES >= 192 && D * Traits<T>::ES <= 256) {
-    if (p.mask == nullptr && (FCSA_DKV_SLOT_MODE == 2 || tile_waves((int64_t)p.B * p.H, p.M, p.causal) != 8)) return launch_dkv_slot<T, D>(p, s);
-  }
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
   } else if constexpr (Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES <= 256) {

@@ -62,12 +62,6 @@ template <> struct Traits<BF16> {
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
-  // The same MFMA with the accumulator pinned in AGPRs (inline asm): for accumulators no VALU instruction touches inside a loop,
-  // next to MFMAs whose results must stay in VGPRs (build flag -amdgpu-mfma-vgpr-form) -- dk / dv of the slot-scheduled dK/dV kernel.
-  // hipcc does not see an MFMA here: whoever READS such an accumulator outside asm lets the pipe drain first (mfma_drain()).
-  static FCSA_DEV void mfma32_agpr(const u32x4& a, const u32x4& b, f32x16& c) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  }
   static FCSA_DEV uint32_t pack2(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(uint32_t, v);
@@ -86,9 +80,6 @@ template <> struct Traits<F16> {
   static constexpr int ES = 2;
   static FCSA_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-  static FCSA_DEV void mfma32_agpr(const u32x4& a, const u32x4& b, f32x16& c) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
   static FCSA_DEV uint32_t pack2(float a, float b) {
     f16x2 v = {(_Float16)a, (_Float16)b};
@@ -282,9 +273,6 @@ template <typename T> struct BiasBlock {
     for (int v = 0; v < NV; ++v) *reinterpret_cast<u32x4*>(dst + 16 * v) = raw[v];
   }
 };
-
-// wait states between the last mfma32_agpr and the first compiler-generated read of its accumulator (16-pass worst case)
-FCSA_DEV void mfma_drain() { asm volatile("s_nop 15\n s_nop 15" ::: "memory"); }
 
 // row index (0..31) of accumulator register r for lane half hi
 FCSA_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
