@@ -16,10 +16,10 @@
 //   * exp2 + masking stay in registers; P~ is packed to 16 bit in place and becomes the
 //     B operand of O^T = V^T P~^T, whose A operand V^T comes from the row-major LDS V tile through
 //     ds_read_b64_tr_b16 (no P~ round trip through shared memory, cf. cu:1222);
-//   * 16-bit types: the row sum comes from the MATRIX pipe -- one extra MFMA per 16-key step with an
-//     all-ones A operand accumulates sum_j P~[j][i] of exactly the rounded P~ that feeds P~V, so O is
-//     a true convex combination of V rows (the reference also sums the rounded tile, cu:1236) and the
-//     VALU, the busier pipe here, loses 32 adds per tile; f32: per-lane adds plus one lane^32 add;
+//   * 16-bit types: the row sum is the exact f32 sum of the ROUNDED P~ that feeds P~V, so O is a true convex combination of
+//     V rows (the reference also sums the rounded tile, cu:1236): v_dot2c against packed ones, 8 per block and lane, one
+//     lane^32 add at the end (round 4; rounds 1 - 3 spent two all-ones MFMAs per block on it, see FCSA_FWD_ROWSUM_VALU);
+//     f32: per-lane adds plus one lane^32 add;
 //   * float32 inputs run the same skeleton on v_mfma_f32_32x32x2_f32 (exact f32, 1/16 of the bf16
 //     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read;
 //   * the key loop is split in two SEQUENTIAL loops, first the tiles that need no masking, then the
@@ -48,6 +48,16 @@ namespace fcsa {
 #define FCSA_FWD_SUB 1
 #endif
 constexpr int kFwdSub = FCSA_FWD_SUB;
+// Row sums of the 16-bit forward forms.  Rounds 1 - 3 took them from the MATRIX pipe (an all-ones MFMA per 16-key step: exact f32 sums of
+// the rounded P~, 2 of a block's 10 MFMAs at D = 64); round 4 takes them from the VALU with v_dot2c_f32_{bf16,f16} against packed ones
+// (the same exact sums: 8 instructions per block and lane, one lane^32 add at the end).  Measured again because the kernels run at the
+// chip's power limit, where a fifth less MFMA work weighs more than eight VALU slots: C3 forward 83.3 -> 77.7 us (-6.7 %), lean D = 128
+// 136.9 -> 129.9, bias form 66.8 -> 63.2, online-reference form 93.8 -> 90.4 (profiles/r04_ab_rowsum_valu.txt).  (Round 2 measured
+// the same swap at +1 % -- before LDS-DMA staging, with the MFMA group hints still counting the two row-sum MFMAs.)
+// Bits: 1 = prefetching form (D <= 64), 2 = lean form (D = 96 / 128), 4 = generic block (bias, f32 keeps its per-lane adds).
+#ifndef FCSA_FWD_ROWSUM_VALU
+#define FCSA_FWD_ROWSUM_VALU 7
+#endif
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
 #endif
@@ -171,10 +181,15 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
     }
   }
   pb.prep(s);
-  if constexpr (TR::ES == 2) {      // lacc[*][i] += sum over this block's 32 keys of the rounded P~
+  if constexpr (TR::ES == 2) {      // row sum of this block's 32 keys, of the ROUNDED P~
+#if FCSA_FWD_ROWSUM_VALU & 4
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l = TR::add_pair(pb.v[e >> 2][e & 3], l);
+#else
     const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
     lacc = TR::mfma32(ones, pb.v[0], lacc);
     lacc = TR::mfma32(ones, pb.v[1], lacc);
+#endif
   }
 }
 
@@ -213,7 +228,9 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
   if constexpr (LEAN) {
     // per 32-key block: K fragments (4 k-steps at a time) -> S chain; V fragments of the block requested behind the chain, landing
     // during exp / pack; row sum on the matrix pipe; PV.  Everything is read from the LDS tile here (`kf` is unused).
+#if !(FCSA_FWD_ROWSUM_VALU & 2)
     const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
+#endif
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
       f32x16 s;
@@ -257,8 +274,13 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       }
       SecondB<T> pb;
       pb.prep(s);
+#if FCSA_FWD_ROWSUM_VALU & 2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l = TR::add_pair(pb.v[e >> 2][e & 3], l);
+#else
       lacc = TR::mfma32(ones, pb.v[0], lacc);
       lacc = TR::mfma32(ones, pb.v[1], lacc);
+#endif
 #pragma unroll
       for (int db = 0; db < G::DB; ++db) {
         o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
@@ -356,9 +378,16 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
         for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(knext, 32 * jb, kk);
     }
     // --- PV of block 0 (row sum + DB output blocks) interleaved with exp / pack of block 1
+#if !(FCSA_FWD_ROWSUM_VALU & 1)
     const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
+#endif
+#if FCSA_FWD_ROWSUM_VALU & 1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l = TR::add_pair(pb0.v[e >> 2][e & 3], l);
+#else
     lacc = TR::mfma32(ones, pb0.v[0], lacc);
     lacc = TR::mfma32(ones, pb0.v[1], lacc);
+#endif
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
       o[db] = TR::mfma32(vf0[db][0], pb0.v[0], o[db]);
@@ -371,7 +400,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       s1[r] = e;
     }
     pb1.prep(s1);
-    constexpr int NPV = 2 + 2 * G::DB;
+    constexpr int NPV = ((FCSA_FWD_ROWSUM_VALU & 1) ? 0 : 2) + 2 * G::DB;
 #pragma unroll
     for (int m = 0; m < NPV; ++m) {
       __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
@@ -381,8 +410,13 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     __builtin_amdgcn_sched_barrier(0);
     FCSA_STAMP(ts, 8);
     // --- PV of block 1
+#if FCSA_FWD_ROWSUM_VALU & 1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l = TR::add_pair(pb1.v[e >> 2][e & 3], l);
+#else
     lacc = TR::mfma32(ones, pb1.v[0], lacc);
     lacc = TR::mfma32(ones, pb1.v[1], lacc);
+#endif
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
       o[db] = TR::mfma32(vf1[db][0], pb1.v[0], o[db]);
@@ -817,7 +851,11 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   // pass may overwrite buffer 0 in its prologue
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
+#if FCSA_FWD_ROWSUM_VALU
+  const float lt = (TR::ES == 2) ? lacc[0] + xhalf_sum(l) : xhalf_sum(l);
+#else
   const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
+#endif
   if (p.splits > 1) {     // un-normalised partial of this key range; fwd_combine_kernel sums, clamps and normalises
     if (i < p.N) {
       const int64_t prow = ((int64_t)blockIdx.y * p.B * p.H + bh) * p.N + i;

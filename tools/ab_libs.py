@@ -11,6 +11,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal[,M[,bias[,mask]]]; several shapes separated by ':'")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--scale", type=float, default=8.0)
 ap.add_argument("tags", nargs="+")
 a = ap.parse_args()
 import ctypes
@@ -46,7 +47,7 @@ def run_shape(shape):
     def step():
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal)).backward(do)
+        F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale).backward(do)
     res = {t: {} for t in a.tags}
     for r in range(a.rounds + 1):
         for t in a.tags:
@@ -68,7 +69,7 @@ def run_shape(shape):
         assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        o = F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal))
+        o = F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale)
         o.backward(do)
         outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
     for t in a.tags[1:]:
