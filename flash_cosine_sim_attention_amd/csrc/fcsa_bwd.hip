@@ -541,7 +541,10 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
         if (sub == 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
         if (sub == SUB / 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
       }
-      if constexpr (TR::ES == 2 && !BIAS && !TWO) {      // pipelined tile: one wave per SIMD only
+#ifndef FCSA_DQ_PIPE_ALL
+#define FCSA_DQ_PIPE_ALL 0
+#endif
+      if constexpr (TR::ES == 2 && !BIAS && (!TWO || FCSA_DQ_PIPE_ALL)) {      // pipelined tile: one wave per SIMD only
         bool skip = false;
         if constexpr (MASKED) skip = causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
