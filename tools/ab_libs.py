@@ -71,9 +71,9 @@ def run_shape(shape):
         if bias is not None: bias.grad = None
         o = F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale)
         o.backward(do)
-        outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad)]
+        outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad) + ((bias.grad,) if bias is not None else ())]
     for t in a.tags[1:]:
-        print(f"{t} vs {a.tags[0]}: max|diff| o/dq/dk/dv = " + " ".join(f"{(x - y).abs().max().item():.3g}" for x, y in zip(outs[t], outs[a.tags[0]])))
+        print(f"{t} vs {a.tags[0]}: max|diff| o/dq/dk/dv[/dbias] = " + " ".join(f"{(x - y).abs().max().item():.3g}" for x, y in zip(outs[t], outs[a.tags[0]])))
     names = ["fwd", "bwd_dq", "bwd_dkv", "bwd_dbias", "finalize", "l2norm"]
     print(f"shape {shape} {a.dtype}; median (min) us over {a.rounds} interleaved rounds")
     for t in a.tags:
