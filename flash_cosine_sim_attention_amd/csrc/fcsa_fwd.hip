@@ -34,6 +34,8 @@
 //   fwd_kernel, gridDim.y = splits  key range split over several workgroups + fwd_combine_kernel (grids that cannot fill the chip)
 //   fwd_kernel<.., LEAN>            16-bit D = 96 / 128 on chip-covering grids: no cross-block prefetch, 256 registers, two waves per SIMD
 //   fwd_kernel<.., KM>              non-causal launches: no causal pairing / diagonal logic, masked tiles in the rank-1 form
+//   fwd_kernel<.., KSPLIT>          128-row workgroups of 8 waves whose halves split the keys (grids of <= one workgroup per CU; 16-bit D = 96 / 128
+//                                   whenever the 256-row lean form cannot cover the chip)
 //   fwd2_kernel                     64 rows per wave, slot-scheduled rotating pipeline (D <= 64, 16 bit, no bias, no key mask; see its header)
 #include <cstdlib>
 #include <type_traits>
@@ -501,7 +503,7 @@ FCSA_DEV void request_q_rows(const FwdParams& p, int b, int h, int i, int hi, u3
 // the backward reads, or the plain c1 scaling
 template <typename T, int D, bool OPQ = false>
 FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const FragAddr<T, D>& fa,
-                             u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS]) {
+                             u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], bool publish = true) {
   typedef TileGeom<D, Traits<T>::ES> G;
   if constexpr (Traits<T>::ES == 2) {
     if (p.q_raw) {
@@ -525,7 +527,7 @@ FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const Frag
         for (int k2 = 0; k2 < G::KS; ++k2) tot += ((k2 >> sh) == (kk >> sh)) ? pair[k2] : 0.f;
         const float r = 1.f / fmaxf(sqrtf(tot), p.norm_eps);
         qf[kk] = scale_frag<T>(qf[kk], r * p.c1);
-        if (i < p.N) {
+        if (i < p.N && publish) {
           const int c = 2 * kk + hi_;
           if (p.qn_out != nullptr) *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];      // (inference: nothing is saved)
           if (p.rq_out != nullptr && (c & ((1 << p.lgm) - 1)) == 0) p.rq_out[row * p.G + (c >> p.lgm)] = r;
@@ -557,20 +559,30 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 // start from -reference instead of the static shift and inv_l is saved as log2(1 / sum_j exp(S_ij)), i.e. for shift 0.
 // KM: the launch is NOT causal (compile-time: a third tile loop in one kernel made hipcc spill 200 registers): tiles that need
 // masking -- a key mask, the ragged last tile -- take the rank-1 MFMA form (fwd_tile MODE 2) instead of the per-logit select.
-template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN, bool KM>
+// KSPLIT (8 waves, lean tile form): the workgroup owns 128 query rows and its two wave halves split the KEYS -- a stage is two 64-key
+// tiles, waves 0-3 take the even tile, waves 4-7 the odd one, for the same four 32-row slices -- and add their (O, l) partials through
+// the LDS at the end of the pass (plain sums: there is no running max to reconcile).  For grids whose 128-row workgroups cannot give
+// every SIMD two waves: 256 four-wave workgroups (C2: 4 x 8 x 1024 rows; C5 at D = 128, where the four-wave form runs ONE wave per
+// SIMD whatever the grid) are one wave per SIMD; this form keeps the grid and doubles the waves, and the partner wave hides what the
+// lean form does not prefetch.
+template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN, bool KM, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
+  static_assert(!KSPLIT || (NW == 8 && LEAN && !DYN && !BIAS && Traits<T>::ES == 2), "key-split form: 8 waves, lean tile, 16 bit, static shift, no bias");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  constexpr int BN = 64, BM = 32 * NW, NT = NW * 64;
+  constexpr int RWAVES = KSPLIT ? NW / 2 : NW;            // waves that own distinct row slices
+  constexpr int BN = 64, BM = 32 * RWAVES, NT = NW * 64;
   constexpr int TILE_B = BN * G::ROWB;
-  constexpr int SUB = fwd_stage_tiles<T, D, DYN>();       // 64-key tiles per stage
+  constexpr int SUB = KSPLIT ? 2 : fwd_stage_tiles<T, D, DYN>();       // 64-key tiles per stage
   constexpr int STAGE_B = 2 * SUB * TILE_B;                // K tiles | V tiles of one stage
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][SUB K tiles | SUB V tiles]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rwave = KSPLIT ? (wave & (RWAVES - 1)) : wave;      // row slice of this wave
+  const int half = KSPLIT ? wave / RWAVES : 0;                  // KSPLIT: which tile of a stage
   FragAddr<T, D> fa;
   fa.init(lane);
 
@@ -614,7 +626,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   FCSA_PASS_MARK(0);
   const int mt = causal ? (pass == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
   const int m0 = mt * BM;
-  const int mw = m0 + wave * 32;                  // first query row of this wave
+  const int mw = m0 + rwave * 32;                 // first query row of this wave
   const int i = mw + (lane & 31);                 // this lane's query row
 
   // key tiles this workgroup needs
@@ -656,7 +668,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
 
   u32x4 qf[G::KS];
   request_q_rows<T, D>(p, b, h, i, fa.hi, qf);
-  finish_q_frags<T, D, LEAN || (BIAS && DYN)>(p, b, h, i, fa, qf);
+  finish_q_frags<T, D, LEAN || (BIAS && DYN)>(p, b, h, i, fa, qf, half == 0);
   FCSA_PASS_MARK(1);
 
   f32x16 o[G::DB];
@@ -715,7 +727,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       sk.load(kbase, p.k.sn, Mk);
       sv.load(vbase, p.v.sn, Mk);
     }
-    if (mrow) mb = lane < Mk ? mrow[lane] : (uint8_t)0;
+    if (mrow) mb = half * BN + lane < Mk ? mrow[half * BN + lane] : (uint8_t)0;
     if constexpr (BIAS_AHEAD) request_bias(0);
   }
   // Every prologue load (Q fragments, first tile, mask byte) is complete here on the real path; say so on ALL
@@ -841,8 +853,55 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       if constexpr (!MASKED) ts.close(10);     // trace: unmasked tiles only
     }
   };
-  run(std::integral_constant<int, 0>{}, 0, t_split);
-  run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
+  if constexpr (!KSPLIT) {
+    run(std::integral_constant<int, 0>{}, 0, t_split);
+    run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
+  } else {
+    // stage u = tiles 2u, 2u + 1; this wave's tile is t = 2u + half.  ONE barrier per stage for every wave, whatever its tile needs:
+    // first the stages whose tile needs no masking, then the others (a stage past this wave's last tile is a bare barrier)
+    const int ns = (nt + 1) / 2;
+    const int u_split = min(ns, max(0, (t_split - half + 1) / 2));
+    auto stage = [&](auto masked_tag, int u) {
+      constexpr int MODE = decltype(masked_tag)::value;
+      const int t = 2 * u + half, j0 = t * BN;
+      const char* buf = smem + (u & 1) * STAGE_B;
+      uint64_t word = 0;
+      if constexpr (MODE != 0) {
+        word = __ballot((j0 + lane) < Mk && mb != 0);
+        if (mrow && t + 2 < nt) {
+          const int key = j0 + 2 * BN + lane;
+          mb = key < Mk ? mrow[key] : (uint8_t)0;
+        }
+      }
+      if (2 * (u + 1) < nt) {      // stage u + 1: its buffer was last read in stage u - 1, which ended with a barrier
+        stk.off += k_step;
+        stv.off += v_step;
+        if (far || (stk.off | stv.off) > DS::REBASE) {
+          stk = dk_.open(kbase + (int64_t)(u + 1) * BN * SUB * p.k.sn, p.k.sn, Mk - (u + 1) * BN * SUB);
+          stv = dv_.open(vbase + (int64_t)(u + 1) * BN * SUB * p.v.sn, p.v.sn, Mk - (u + 1) * BN * SUB);
+        }
+        const uint32_t lds_nxt = lds0 + ((u + 1) & 1) * STAGE_B;
+        dk_.issue(stk, lds_nxt, wave);
+        dv_.issue(stv, lds_nxt + SUB * TILE_B, wave);
+      }
+      auto mid = [&]() {
+        dma_wait();
+        FCSA_BAR_BEGIN(bar_t);
+        __syncthreads();
+        FCSA_BAR_END(bar_t, bar_wait);
+      };
+      bool skip = t >= nt;
+      if constexpr (MODE == 1) skip = skip || (causal && j0 > mw + 31 + diff);
+      if (skip) {
+        mid();
+        return;
+      }
+      fwd_tile<T, D, MODE, BIAS, LEAN, DYN>(buf + (SUB + half) * TILE_B, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid,
+                                           nullptr, false, buf + half * TILE_B);
+    };
+    for (int u = 0; u < u_split; ++u) stage(std::integral_constant<int, 0>{}, u);
+    for (int u = u_split; u < ns; ++u) stage(std::integral_constant<int, KM ? 2 : 1>{}, u);
+  }
   FCSA_PASS_MARK(3);
 #ifdef FCSA_TRACE_BAR
   FCSA_BAR_END(loop_t, bar_loop);
@@ -852,10 +911,44 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
 #if FCSA_FWD_ROWSUM_VALU
-  const float lt = (TR::ES == 2) ? lacc[0] + xhalf_sum(l) : xhalf_sum(l);
+  float lt = (TR::ES == 2) ? lacc[0] + xhalf_sum(l) : xhalf_sum(l);
 #else
-  const float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
+  float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
 #endif
+  if constexpr (KSPLIT) {
+    // the odd-tile half hands its partials to the even-tile half of the same rows through the LDS (the staging buffers are free:
+    // every wave's last LDS read came before the last stage barrier); 16-byte accesses, lane-contiguous
+    constexpr int NV = G::DB * 4 + 1;                                  // f32x4 per lane: O^T accumulators + (l, -, -, -)
+    f32x4* ms = reinterpret_cast<f32x4*>(smem) + rwave * (NV * 64) + lane;
+    if (half == 1) {
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
+          ms[(db * 4 + g) * 64] = v;
+        }
+      const f32x4 lv = {lt, 0.f, 0.f, 0.f};
+      ms[(NV - 1) * 64] = lv;
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = ms[(db * 4 + g) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[db][4 * g + e] += v[e];
+        }
+      lt += ms[(NV - 1) * 64][0];
+    }
+    __syncthreads();                                                    // (the row epilogue's scratch overlays what was just read)
+    if (half == 1) {
+      if (pass + 1 < npass) __syncthreads();
+      continue;
+    }
+  }
   if (p.splits > 1) {     // un-normalised partial of this key range; fwd_combine_kernel sums, clamps and normalises
     if (i < p.N) {
       const int64_t prow = ((int64_t)blockIdx.y * p.B * p.H + bh) * p.N + i;
@@ -874,7 +967,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   {
     typedef RowEpilogue<T, D> EP;
     if (p.N - mw > 0)
-      EP::store(smem + wave * EP::BYTES_NOX, o, inv, (LEAN || (BIAS && DYN)) ? opaque(lane) : lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
+      EP::store(smem + rwave * EP::BYTES_NOX, o, inv, (LEAN || (BIAS && DYN)) ? opaque(lane) : lane, p.o.p + (int64_t)b * p.o.sb + (int64_t)h * p.o.sh + (int64_t)mw * p.o.sn, p.o.sn,
                 p.N - mw, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
     if (pass + 1 < npass) __syncthreads();
   }
@@ -1254,6 +1347,26 @@ static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
 
+// Key-split form (fwd_kernel<.., KSPLIT>): 128-row workgroups of 8 waves.  Where the 128-row four-wave workgroups would leave the SIMDs
+// with one wave each: rows wider than 128 bytes always (that form runs one wave per SIMD whatever the grid), narrower rows when the grid
+// has fewer than ~1.5 workgroups per CU.
+#ifndef FCSA_FWD_KSPLIT
+#define FCSA_FWD_KSPLIT 1
+#endif
+template <typename T, int D, bool BIAS> constexpr bool fwd_ksplit() {
+  return FCSA_FWD_KSPLIT != 0 && Traits<T>::ES == 2 && !BIAS && (D == 64 || D == 96 || D == 128) && (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
+}
+template <typename T, int D>
+static bool use_ksplit_fwd(const FwdParams& p) {
+  const int MT = (p.N + 127) / 128;
+  const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
+  if (D * Traits<T>::ES > 128) return true;
+#ifndef FCSA_KSPLIT_WGS
+#define FCSA_KSPLIT_WGS 256
+#endif
+  return wgs <= FCSA_KSPLIT_WGS;
+}
+
 // Split-key forward, second step: O = (sum_s partial P~V) / max(sum_s partial l, eps), inv_l alike.  One thread per
 // (row, 8 features); the partials are a few MB and L2-resident.
 template <typename T, int D>
@@ -1293,22 +1406,23 @@ __global__ void __launch_bounds__(256) fwd_combine_kernel(const FwdParams p) {
   if (c == 0 && p.inv_l != nullptr) p.inv_l[row] = inv;
 }
 
-template <typename T, int D, bool BIAS, int NW, bool DYN, bool LEAN = false>
+template <typename T, int D, bool BIAS, int NW, bool DYN, bool LEAN = false, bool KSPLIT = false>
 static hipError_t launch_fwd_nw(const FwdParams& p, hipStream_t s) {
-  constexpr int BM = 32 * NW;
+  constexpr int RWAVES = KSPLIT ? NW / 2 : NW, BM = 32 * RWAVES;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
-  size_t lds = 4 * 64 * fwd_stage_tiles<T, D, DYN>() * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K + V tiles of a stage)
-  if (lds < (size_t)NW * RowEpilogue<T, D>::BYTES_NOX) lds = (size_t)NW * RowEpilogue<T, D>::BYTES_NOX;   // epilogue scratch reuses the same bytes
+  size_t lds = 4 * 64 * (KSPLIT ? 2 : fwd_stage_tiles<T, D, DYN>()) * TileGeom<D, Traits<T>::ES>::ROWB;      // 2 buffers x (K + V tiles of a stage)
+  if (lds < (size_t)RWAVES * RowEpilogue<T, D>::BYTES_NOX) lds = (size_t)RWAVES * RowEpilogue<T, D>::BYTES_NOX;   // epilogue scratch reuses the same bytes
+  if (KSPLIT && lds < (size_t)RWAVES * 64 * 16 * (TileGeom<D, Traits<T>::ES>::DB * 4 + 1)) lds = (size_t)RWAVES * 64 * 16 * (TileGeom<D, Traits<T>::ES>::DB * 4 + 1);
   // two instantiations: causal launches (select per logit on the diagonal tiles) and the others (key masks as a rank-1 MFMA)
   const dim3 grid((unsigned)(p.B * p.H * PT), (unsigned)(p.splits > 1 ? p.splits : 1));
   if (p.causal) {
-    auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN, false>;
+    auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN, false, KSPLIT>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
   } else {
-    auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN, true>;
+    auto kern = fwd_kernel<T, D, NW, BIAS, DYN, LEAN, true, KSPLIT>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
@@ -1337,6 +1451,9 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   } else if constexpr (fwd_lean<T, D, BIAS>()) {
     // the lean form needs its partner wave: one 8-wave workgroup per CU (a grid with two 4-wave workgroups per CU always has that)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
+  }
+  if constexpr (fwd_ksplit<T, D, BIAS>()) {
+    if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, true, true>(p, s);
   }
   return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
 }

@@ -207,6 +207,18 @@ NAMED_CASES = [
     _named("X8_bf16_bound70_bias_takes_online", groups=8, scale=8.75, D=64, N=100, M=140, bias=True, seed=108),
     _named("X9_bf16_bound96_online", groups=8, scale=12.0, D=128, N=257, M=257, causal=True, seed=109),
     _named("X10_bf16_long_n_short_m_groups_mask", B=1, H=2, groups=2, scale=8.0, D=64, N=2500, M=200, mask=True, seed=110),
+    # the key-split forward (fcsa_fwd.hip, KSPLIT: two wave halves take the even / odd 64-key tile of a stage): one tile only (the odd
+    # half idles), odd and even tile counts, ragged tails, diagonal tiles in either half, key masks, every head dim that has the form
+    _named("K1_bf16_d64_one_tile", groups=1, D=64, N=128, M=64, seed=201),
+    _named("K2_bf16_d64_three_tiles_causal", groups=1, D=64, N=200, M=192, causal=True, B=2, H=3, seed=202),
+    _named("K3_f16_d64_five_tiles_ragged_mask", dtype="f16", groups=1, D=64, N=100, M=257, mask=True, B=2, seed=203),
+    _named("K4_bf16_d128_causal_m_gt_n", groups=1, D=128, N=129, M=300, causal=True, seed=204),
+    _named("K5_f16_d96_causal", dtype="f16", groups=1, D=96, N=257, M=257, causal=True, seed=205),
+    _named("K6_bf16_d128_single_kv_mask", groups=1, D=128, N=64, M=1000, mask=True, single_kv=True, H=3, seed=206),
+    _named("K7_f16_d64_groups2_causal", dtype="f16", groups=2, D=64, N=300, M=300, causal=True, B=3, H=5, seed=207),
+    _named("K8_bf16_d64_one_row", groups=1, D=64, N=1, M=130, seed=208),
+    _named("K9_bf16_d64_causal_n_gt_m", groups=1, D=64, N=400, M=130, causal=True, seed=209),
+    _named("K10_f16_d128_two_tiles", dtype="f16", groups=4, D=128, N=333, M=128, seed=210),
 ]
 
 
