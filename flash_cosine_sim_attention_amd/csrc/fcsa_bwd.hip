@@ -229,9 +229,9 @@ FCSA_DEV void dq_tile_pipe(const char* kt, const char* vt, const char* knext, co
 template <typename T, int D> constexpr bool dq_dma(int sub) {
   return (Traits<T>::ES == 2 || D * Traits<T>::ES >= 512) && (64 * sub * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
 }
-template <typename T, int D, int NW, int SUB, bool TWO> struct DqLds
+template <typename T, int D, int NW, int SUB, bool TWO, bool WHOLE_CU = false> struct DqLds      // (NW: waves with an epilogue of their own)
     : EpiLds<T, D, NW, 4 * 64 * SUB * TileGeom<D, Traits<T>::ES>::ROWB, dq_dma<T, D>(SUB),
-             ((NW == 8 || !TWO) ? 160 : 80) * 1024> {};
+             ((NW == 8 || !TWO || WHOLE_CU) ? 160 : 80) * 1024> {};
 
 // LDS plan of the dKV kernel: two staging buffers of (Q tile | dO tile | lc | -delta), epilogue scratch behind them when it fits.
 // LEAN (16-bit rows of 129 .. 256 bytes, two waves per SIMD): the V rows of the workgroup's own keys live in the LDS behind the staging
@@ -248,12 +248,17 @@ template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false, int 
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
 // KM: the launch is not causal; tiles that need masking take the rank-1 form (see fwd_kernel)
-template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO, bool KM>
+// KSPLIT (8 waves, the two-wave tile, SUB = 2): the workgroup owns 128 query rows and its wave halves split the KEYS -- waves 0-3 take
+// the even 64-key tile of a stage, waves 4-7 the odd one -- and add their dQ partials through the LDS at the end of the pass (see
+// fwd_kernel, KSPLIT): for grids of at most one 128-row workgroup per CU, whose four waves would each have a SIMD to themselves.
+template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO, bool KM, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
+  static_assert(!KSPLIT || (NW == 8 && TWO && !BIAS && SUB == 2 && Traits<T>::ES == 2), "key-split form: 8 waves, two-wave tile, 16 bit, no bias, 2 tiles per stage");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  constexpr int BN = 64, BM = 32 * NW, NT = NW * 64, BNS = BN * SUB;
+  constexpr int RWAVES = KSPLIT ? NW / 2 : NW;      // waves that own distinct row slices
+  constexpr int BN = 64, BM = 32 * RWAVES, NT = NW * 64, BNS = BN * SUB;
   constexpr int TILE_B = BN * G::ROWB;          // one 64-key tile of K or V
   constexpr int HALF_B = SUB * TILE_B;          // K (or V) part of a stage
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K stage | V stage]
@@ -261,6 +266,8 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rwave = KSPLIT ? (wave & (RWAVES - 1)) : wave;      // row slice of this wave
+  const int half = KSPLIT ? wave / RWAVES : 0;                  // KSPLIT: which tile of a stage
   FragAddr<T, D> fa;
   fa.init(lane);
 
@@ -302,7 +309,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   // be finished before the next one starts loading: the first K / V stage and this lane's Q^ / dO / O row chunks of the NEXT
   // iteration are requested before the epilogue of the current one and land while it runs (the pass marks of the WG trace showed
   // 11 % of this kernel in prologues and 7 % in epilogues: exposed round trips, every workgroup of the chip in step).
-  typedef DqLds<T, D, NW, SUB, TWO> LDS;
+  typedef DqLds<T, D, RWAVES, SUB, TWO, KSPLIT> LDS;
   constexpr bool SEP = LDS::SEP;
   Stager<T, D, BNS, NT> sk, sv;
   typedef DmaStager<T, D, DMA ? BNS : 1024, NW> DS;
@@ -342,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   // that tile publishes them.  Needs piece i of every wave == tile i of the stage.  (A stage requested from inside the previous
   // pass's epilogue is not split: its flight is covered.)
   // (not with a bias: its loads inside the tile would be younger than the stage pieces the counted wait must leave in flight)
-  constexpr bool SPLIT0 = DMA && !BIAS && SUB > 1 && DS::PER == SUB && (NW * 1024) / G::ROWB == BN && kDqSplitFirstStage;
+  constexpr bool SPLIT0 = !KSPLIT && DMA && !BIAS && SUB > 1 && DS::PER == SUB && (NW * 1024) / G::ROWB == BN && kDqSplitFirstStage;
   bool split0 = false;
   auto request_ahead = [&](int b_, int h_, int pass_, bool cold) {
     int m0_, nt_;
@@ -363,7 +370,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     }
     if constexpr (!SEP) return;      // (without SEP the rows are loaded where they are used: fewer registers live at once)
     const int ln = opaque(lane), hi_ = ln >> 5;
-    const int i_ = m0_ + wave * 32 + (ln & 31);
+    const int i_ = m0_ + rwave * 32 + (ln & 31);
     const char* qrow = p.q.p + (int64_t)b_ * p.q.sb + (int64_t)h_ * p.q.sh + (int64_t)i_ * p.q.sn;
     const char* dorow = p.d_out.p + (int64_t)b_ * p.d_out.sb + (int64_t)h_ * p.d_out.sh + (int64_t)i_ * p.d_out.sn;
     const char* orow = p.o.p + (int64_t)b_ * p.o.sb + (int64_t)h_ * p.o.sh + (int64_t)i_ * p.o.sn;
@@ -382,10 +389,10 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     rinvl = i_ < p.N ? p.inv_l[((int64_t)b_ * p.H + h_) * p.N + i_] : 1.f;
     // inverse norms of the rows this lane FINISHES in the epilogue (fused l2norm backward): loaded here, carried through the tile
     // loops (NP registers), so that the epilogue has no global read to wait for
-    const int rows_valid_ = p.N - (m0_ + wave * 32);
+    const int rows_valid_ = p.N - (m0_ + rwave * 32);
     typedef RowEpilogue<T, D> EP;
     if (p.rq != nullptr && rows_valid_ > 0)
-      EP::load_inv(rinv_n, p.rq + (((int64_t)b_ * p.H + h_) * p.N + m0_ + wave * 32) * p.G, p.G, p.lgm, ln, rows_valid_);
+      EP::load_inv(rinv_n, p.rq + (((int64_t)b_ * p.H + h_) * p.N + m0_ + rwave * 32) * p.G, p.G, p.lgm, ln, rows_valid_);
   };
 
 #ifdef FCSA_TRACE_BAR
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   FCSA_PASS_MARK(0);
   int m0, nt;
   geometry(pass, m0, nt);
-  const int mw = m0 + wave * 32;
+  const int mw = m0 + rwave * 32;
   const int i = mw + (lane & 31);
   const char* kbase = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)k_lo * p.k.sn;
   const char* vbase = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)k_lo * p.v.sn;
@@ -438,7 +445,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   if (i < p.N) {
     const int64_t ridx = ((int64_t)b * p.H + h) * p.N + i;
     lc = (p.invl_log2 ? rinvl : __builtin_amdgcn_logf(rinvl)) - p.c2;     // v_log_f32 = log2
-    if (fa.hi == 0 && blockIdx.y == 0) p.delta[ridx] = delta;
+    if (fa.hi == 0 && blockIdx.y == 0 && half == 0) p.delta[ridx] = delta;
   }
 
   f32x16 dq[G::DB];
@@ -463,7 +470,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
       sk.load(kbase, p.k.sn, Mk);
       sv.load(vbase, p.v.sn, Mk);
     }
-    if (mrow) mb = lane < Mk ? mrow[lane] : (uint8_t)0;
+    if (mrow) mb = half * BN + lane < Mk ? mrow[half * BN + lane] : (uint8_t)0;
     if constexpr (DMA) {
       dma_wait();
     } else {
@@ -583,13 +590,80 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
     }
   };
   FCSA_PASS_MARK(1);
-  run(std::integral_constant<int, 0>{}, 0, t_split);
-  FCSA_PASS_MARK(2);
-  run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
+  if constexpr (!KSPLIT) {
+    run(std::integral_constant<int, 0>{}, 0, t_split);
+    FCSA_PASS_MARK(2);
+    run(std::integral_constant<int, KM ? 2 : 1>{}, t_split, nt);
+  } else {
+    // stage u = tiles 2u, 2u + 1; this wave's tile is t = 2u + half; one barrier per stage for every wave (see fwd_kernel, KSPLIT)
+    const int u_split = min(nst, max(0, (t_split - half + 1) / 2));
+    auto stage = [&](auto masked_tag, int u) {
+      constexpr int MODE = decltype(masked_tag)::value;
+      const int t = 2 * u + half, j0 = t * BN;
+      const char* kcur = smem + (u & 1) * 2 * HALF_B + half * TILE_B;
+      const char* vcur = kcur + HALF_B;
+      const bool more = u + 1 < nst;
+      uint64_t word = 0;
+      if constexpr (MODE != 0) {
+        word = __ballot((j0 + lane) < Mk && mb != 0);
+        if (mrow && t + 2 < nt) {
+          const int key = j0 + 2 * BN + lane;
+          mb = key < Mk ? mrow[key] : (uint8_t)0;
+        }
+      }
+      if (more) {       // the buffer of stage u + 1 was last read in stage u - 1, which ended with a barrier
+        stk.off += k_step;
+        stv.off += v_step;
+        if (far || (stk.off | stv.off) > DS::REBASE) {
+          stk = dk_.open(kbase + (int64_t)(u + 1) * BNS * p.k.sn, p.k.sn, Mk - (u + 1) * BNS);
+          stv = dv_.open(vbase + (int64_t)(u + 1) * BNS * p.v.sn, p.v.sn, Mk - (u + 1) * BNS);
+        }
+        const uint32_t lds_nxt = lds0 + ((u + 1) & 1) * 2 * HALF_B;
+        dk_.issue(stk, lds_nxt, wave);
+        dv_.issue(stv, lds_nxt + HALF_B, wave);
+      }
+      bool skip = t >= nt;
+      if constexpr (MODE == 1) skip = skip || (causal && j0 > mw + 31 + diff);
+      if (!skip) dq_tile<T, D, MODE, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
+      if (more) dma_wait();
+      FCSA_BAR_BEGIN(bar_t);
+      __syncthreads();
+      FCSA_BAR_END(bar_t, bar_wait);
+    };
+    for (int u = 0; u < u_split; ++u) stage(std::integral_constant<int, 0>{}, u);
+    FCSA_PASS_MARK(2);
+    for (int u = u_split; u < nst; ++u) stage(std::integral_constant<int, KM ? 2 : 1>{}, u);
+  }
   FCSA_PASS_MARK(3);
 #ifdef FCSA_TRACE_BAR
   FCSA_BAR_END(loop_t, bar_loop);
 #endif
+  if constexpr (KSPLIT) {
+    // the odd-tile half hands its dQ partials to the even-tile half of the same rows (the staging buffers are free: every stage ended
+    // with a barrier); done before anything of the epilogue or the next pass touches the LDS
+    f32x4* ms = reinterpret_cast<f32x4*>(smem) + rwave * (G::DB * 4 * 64) + lane;
+    if (half == 1) {
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
+          ms[(db * 4 + g) * 64] = v;
+        }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = ms[(db * 4 + g) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dq[db][4 * g + e] += v[e];
+        }
+    }
+    __syncthreads();
+  }
 
   // Epilogue through the LDS (RowEpilogue): every stage ended with a barrier, so no wave still reads the staging buffers.
   // With SEP, what the NEXT iteration needs from memory is requested between the epilogue's steps -- after the accumulators went to
@@ -597,9 +671,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   // global memory (inverse norms: loaded with the row chunks; normalised rows: qf, still live), so it never waits for them.
   {
     typedef RowEpilogue<T, D> EP;
-    char* scr = LDS::scratch(smem, wave);
-    char* xs = LDS::xarea(smem, wave);
-    const int rows_valid = p.N - mw;
+    char* scr = LDS::scratch(smem, rwave);
+    char* xs = LDS::xarea(smem, rwave);
+    const int rows_valid = half == 0 ? p.N - mw : 0;      // (KSPLIT: the odd half has handed its partials over and only takes part in the requests)
     const bool fused = p.rq != nullptr;      // dq = l2norm_backward(scale * dS K^): p.q holds c1 * q^ (or q^), contiguous rows
     const bool xreg = LDS::X && fused;      // (fused implies l2norm_qk, i.e. q_scaled: qf is exactly the stored row c1 * q^)
     const int le = opaque(lane);
@@ -966,12 +1040,14 @@ struct DkvPipe {
 // fragments are requested during the last block's M2 products, i.e. BEFORE the tile barrier, and the first chains of a tile start
 // right behind it.  (Two buffers: that request sits at the top of the tile, exposed -- block 0 of a tile took 1320 ticks against 880
 // for the others, phase trace.)  `fresh`: nothing is in flight for this tile (first tile of a pass, or the previous one was skipped).
-template <typename T, int D, int BMQ, int MODE, bool RING = false>
+// QS (query-split form of the kernel): this wave works on BMQ rows of a staged tile of 2 * BMQ, starting `hq` rows (`hoff` bytes) into it;
+// qt / dot / lcs / dls point at its share already, `nxt` at the next staged tile's start
+template <typename T, int D, int BMQ, int MODE, bool RING = false, bool QS = false>
 FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, const float* dls, const FragAddr<T, D>& fa,
                             const u32x4 (&kf)[TileGeom<D, Traits<T>::ES>::KS], const u32x4 (&vf)[TileGeom<D, Traits<T>::ES>::KS],
                             f32x16 (&dk)[TileGeom<D, Traits<T>::ES>::DB], f32x16 (&dv)[TileGeom<D, Traits<T>::ES>::DB],
                             uint32_t kmask, uint32_t ncm, int j, int i0, int diff, Trace& ts, DkvPipe<T, D, BMQ>& pp_, bool fresh = true,
-                            const char* nxt = nullptr, bool young = false) {
+                            const char* nxt = nullptr, bool young = false, int hoff = 0, int hq = 0) {
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr bool MASKED = MODE == 1, KEYM = MODE == 2;
@@ -1025,8 +1101,11 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     // ---- R: next block's row fragments (their registers are dead now); RING: behind the last block, block 0 of the next tile
     if (ib + 1 < NB) pp_.request(qt, dot, lcs, dls, fa, ib + 1);
     else if constexpr (RING) {
-      constexpr int TB = BMQ * G::ROWB;
-      pp_.request(nxt, nxt + TB, reinterpret_cast<const float*>(nxt + 2 * TB), reinterpret_cast<const float*>(nxt + 2 * TB) + BMQ, fa, 0);
+      constexpr int BMT = QS ? 2 * BMQ : BMQ, TB = BMT * G::ROWB;
+      if constexpr (QS)
+        pp_.request(nxt + hoff, nxt + TB + hoff, reinterpret_cast<const float*>(nxt + 2 * TB) + hq, reinterpret_cast<const float*>(nxt + 2 * TB) + BMT + hq, fa, 0);
+      else
+        pp_.request(nxt, nxt + TB, reinterpret_cast<const float*>(nxt + 2 * TB), reinterpret_cast<const float*>(nxt + 2 * TB) + BMQ, fa, 0);
     }
     // ---- M2: dV^T += dO^T P, dK^T += Q^T dS
 #pragma unroll
@@ -1052,12 +1131,18 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
 }
 
 // RING: three staging buffers instead of two and the tile pipeline crosses the tile barrier (dkv_tile_pipe); pipelined LDS-DMA form only
-template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM, bool RING = false>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)
+// QSPLIT (8 waves, ring form): the workgroup owns 128 keys and its wave halves split the QUERIES of every staged tile -- waves 0-3 take its
+// first BMQ / 2 rows, waves 4-7 the others, for the same four 32-key slices -- and add their dK / dV partials through the LDS at the end of
+// the pass: the mirror image of the key-split forward / dQ forms, for grids of at most one 128-key workgroup per CU.
+template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM, bool RING = false, bool QSPLIT = false>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes || LEAN) ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
+  static_assert(!QSPLIT || (NW == 8 && RING && !BIAS && !LEAN && BMQ % 64 == 0), "query-split form: 8 waves, pipelined ring tile");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
-  constexpr int BNK = 32 * NW, NT = NW * 64;
+  constexpr int RWAVES = QSPLIT ? NW / 2 : NW;      // waves that own distinct key slices
+  constexpr int BMS = QSPLIT ? BMQ / 2 : BMQ;       // rows of a staged tile one wave works on
+  constexpr int BNK = 32 * RWAVES, NT = NW * 64;
   constexpr int TILE_B = BMQ * G::ROWB;
   static_assert(!LEAN || (Traits<T>::ES == 2 && !BIAS), "lean form: 16-bit types without bias");
   constexpr bool PIPE = Traits<T>::ES == 2 && !BIAS && !LEAN;      // software-pipelined tile (dkv_tile_pipe)
@@ -1070,6 +1155,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rwave = QSPLIT ? (wave & (RWAVES - 1)) : wave;      // key slice of this wave
+  const int half = QSPLIT ? wave / RWAVES : 0;
+  const int hq = half * BMS, hoff = hq * G::ROWB;               // QSPLIT: this wave's rows inside a staged tile
   FragAddr<T, D> fa;
   fa.init(lane);
 
@@ -1203,7 +1291,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       dvown_.issue(p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)n0_ * p.v.sn, p.v.sn, p.M - n0_, smem + LDS::VOWN, wave);
     }
     const int ln = opaque(lane), hi_ = ln >> 5;
-    const int nw_ = n0_ + wave * 32, j_ = nw_ + (ln & 31);
+    const int nw_ = n0_ + rwave * 32, j_ = nw_ + (ln & 31);
     const char* krow = p.k.p + (int64_t)b * p.k.sb + (int64_t)h * p.k.sh + (int64_t)j_ * p.k.sn;
     const char* vrow = p.v.p + (int64_t)b * p.v.sb + (int64_t)h * p.v.sh + (int64_t)j_ * p.v.sn;
 #pragma unroll
@@ -1231,7 +1319,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   FCSA_PASS_MARK(0);
   int n0, t0;
   geometry(pass, n0, t0);
-  const int nw = n0 + wave * 32;                        // first key of this wave
+  const int nw = n0 + rwave * 32;                       // first key of this wave
   const int j = nw + (lane & 31);                       // this lane's key
   const char* bias_col = nullptr;                 // &bias[slice][0][0] (wave-uniform: the element-load fallback adds row and column itself)
   const char* bias_blk = nullptr;                 // &bias[slice][0][first key of this wave]
@@ -1310,14 +1398,14 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   int t_m = QT;
   if (!BIAS && p.mask == nullptr && n0 + BNK <= p.M) {
     t_m = t0;
-    if (causal) t_m = min(QT, max(t0, (nw + 31 - diff + BMQ - 1) / BMQ));
+    if (causal) t_m = min(QT, max(t0, (nw + 31 - diff - hq + BMQ - 1) / BMQ));      // (QSPLIT: of this wave's rows of the tile)
   }
 
 #ifdef FCSA_TRACE_BAR
   unsigned long long bar_t = 0, loop_t = 0;
   FCSA_BAR_BEGIN(loop_t);
 #endif
-  DkvPipe<T, D, BMQ> pipe;      // RING: lives across the tiles of a pass
+  DkvPipe<T, D, BMS> pipe;      // RING: lives across the tiles of a pass
   int pipe_tile = -1;           // RING: the tile whose first block's fragments are in flight
   int ring = 0;                 // RING: staging buffer of the current tile (t - t0 mod 3, kept without a division)
   auto run = [&](auto masked_tag, int t_begin, int t_end) {
@@ -1355,11 +1443,15 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
       }
       {
       bool skip = false;
-      if constexpr (MASKED) skip = causal && (i0 + BMQ - 1 + diff < nw);  // no valid pair for this wave
+      if constexpr (MASKED) skip = causal && (i0 + hq + BMS - 1 + diff < nw);  // no valid pair for this wave
       if constexpr (PIPE) {
         if constexpr (RING) {
           if (!skip) {
             const bool has_next = t + 1 < QT;      // (else: the request reads this tile's buffer again and is never used)
+            if constexpr (QSPLIT)
+              dkv_tile_pipe<T, D, BMS, MODE, true, true>(cur + hoff, cur + TILE_B + hoff, lcs + hq, dls + hq, fa, kf, vf, dk, dv, kmask, ncm, j, i0 + hq, diff, ts,
+                                                          pipe, pipe_tile != t, has_next ? smem + par_nxt * BUF_B : cur, wave >= 4, hoff, hq);
+            else
             dkv_tile_pipe<T, D, BMQ, MODE, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, pipe_tile != t,
                                                   has_next ? smem + par_nxt * BUF_B : cur, NW == 8 && wave >= 4);
             pipe_tile = has_next ? t + 1 : -1;
@@ -1401,13 +1493,41 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
   FCSA_BAR_END(loop_t, bar_loop);
 #endif
 
+  if constexpr (QSPLIT) {
+    // the second-half waves hand their dK / dV partials to the first-half waves of the same keys (the staging buffers are free: every
+    // tile ended with a barrier); done before anything of the epilogue or the next pass touches the LDS
+    f32x4* ms = reinterpret_cast<f32x4*>(smem) + rwave * (G::DB * 8 * 64) + lane;
+    if (half == 1) {
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 a = {dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]};
+          const f32x4 c = {dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]};
+          ms[(db * 8 + g) * 64] = a;
+          ms[(db * 8 + 4 + g) * 64] = c;
+        }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 a = ms[(db * 8 + g) * 64], c = ms[(db * 8 + 4 + g) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dk[db][4 * g + e] += a[e]; dv[db][4 * g + e] += c[e]; }
+        }
+    }
+    __syncthreads();
+  }
   // Epilogue through the LDS (RowEpilogue): every tile ended with a barrier, so no wave still reads the staging buffers.
   // With SEP the next pass is requested between its steps and the epilogue reads nothing from global memory (see bwd_dq_kernel).
   {
     typedef RowEpilogue<T, D> EP;
-    char* scr = LDS::scratch(smem, wave);
-    char* xs = LDS::xarea(smem, wave);
-    const int rows_valid = p.M - nw;
+    char* scr = LDS::scratch(smem, rwave);
+    char* xs = LDS::xarea(smem, rwave);
+    const int rows_valid = half == 0 ? p.M - nw : 0;      // (QSPLIT: the second half has handed its partials over)
     const bool fused = p.rk != nullptr;      // dk = l2norm_backward(dKh): p.k holds k^ (K/V with heads only), kf = this wave's rows of it
     const int le = opaque(lane);
     // dKh = scale * dS^T Qh; when the Q tile holds c1 * qh the factor becomes scale / c1 (= ln 2)
@@ -1495,6 +1615,17 @@ extern "C" int fcsa_trace_read_dkv(unsigned long long* out) {
 namespace fcsa {
 #endif
 
+// key-split forms of the backward kernels (bwd_dq_kernel<.., KSPLIT>): 16-bit, no bias, the head dims the forward has it for
+#ifndef FCSA_BWD_KSPLIT
+#define FCSA_BWD_KSPLIT 1
+#endif
+template <typename T, int D, bool BIAS> constexpr bool bwd_ksplit() {
+#ifndef FCSA_BWD_KSPLIT_WIDE
+#define FCSA_BWD_KSPLIT_WIDE 1
+#endif
+  return FCSA_BWD_KSPLIT != 0 && Traits<T>::ES == 2 && !BIAS && (D == 64 || (FCSA_BWD_KSPLIT_WIDE != 0 && (D == 96 || D == 128)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
 static int tile_waves(int64_t batch_heads, int len, bool causal) {
@@ -1502,27 +1633,28 @@ static int tile_waves(int64_t batch_heads, int len, bool causal) {
   return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
 }
 
-template <typename T, int D, bool BIAS, int NW, bool TWO>
+template <typename T, int D, bool BIAS, int NW, bool TWO, bool KSPLIT = false>
 static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
-  constexpr int BM = 32 * NW;
+  constexpr int RWAVES = KSPLIT ? NW / 2 : NW, BM = 32 * RWAVES;
   const int MT = (p.N + BM - 1) / BM;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   // 128-key stages (one barrier per 128 keys) in the 8-wave form and, with LDS-DMA staging (no staging registers), also for the
   // one-wave-per-SIMD configurations (16-bit D >= 96: one workgroup per CU, the LDS is there)
   // 8-wave form: 256-key stages where they arrive by LDS-DMA (no staging registers), 128-key stages through registers (f32)
-  constexpr int SUB = NW == 8 ? (Traits<T>::ES == 2 ? kDqSub8 : 2) : 1;
-  const size_t lds = DqLds<T, D, NW, SUB, TWO>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
+  constexpr int SUB = KSPLIT ? 2 : NW == 8 ? (Traits<T>::ES == 2 ? kDqSub8 : 2) : 1;
+  size_t lds = DqLds<T, D, RWAVES, SUB, TWO, KSPLIT>::TOTAL;      // 2 buffers x (K stage + V stage), epilogue scratch behind or inside them
+  if (KSPLIT && lds < (size_t)RWAVES * 64 * 16 * TileGeom<D, Traits<T>::ES>::DB * 4) lds = (size_t)RWAVES * 64 * 16 * TileGeom<D, Traits<T>::ES>::DB * 4;
   const dim3 grid((unsigned)((int64_t)p.B * p.H * PT), (unsigned)(p.dq_splits > 1 ? p.dq_splits : 1));
   // (two instantiations, see launch_fwd_nw.  The two-wave form of 256-byte rows sits at its 256 registers: its non-causal
   //  instantiation came out with spill reloads inside the tile loops -- +5.6 % time -- so those launches keep the general kernel)
   constexpr bool GENERAL_ONLY = TWO && D * Traits<T>::ES >= 256;      // (its non-causal twin is not even instantiated)
   if (p.causal || GENERAL_ONLY) {
-    auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, false>;
+    auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, false, KSPLIT>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
   } else if constexpr (!GENERAL_ONLY) {
-    auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, true>;
+    auto kern = bwd_dq_kernel<T, D, NW, BIAS, SUB, TWO, true, KSPLIT>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
@@ -1533,21 +1665,30 @@ static hipError_t launch_dq_nw(const BwdParams& p, hipStream_t s) {
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   constexpr bool NARROW = D * Traits<T>::ES <= kDq2WBytes;      // rows <= 128 bytes: two waves per SIMD whatever the grid
-  if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges
+  if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges (the key-split form measured level there)
   if constexpr (NARROW) {
     if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
+    if constexpr (bwd_ksplit<T, D, BIAS>()) {      // at most one 128-row workgroup per CU: its wave halves split the keys
+      const int MT4 = (p.N + 127) / 128;
+      if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= 256) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
+    }
   } else if constexpr (dq_can_two_waves<T, D>() && !BIAS) {
     // two waves per SIMD need two 128-row workgroups on every CU; smaller grids keep the one-wave (pipelined) form
     // (bias launches keep the one-wave form too: their two-wave instantiation spills 17 registers and was never measured ahead)
     const int MT4 = (p.N + 127) / 128;
     if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= 448) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
+    // fewer: the same tile, 8 waves on 128 rows.  Causal launches only: 256-byte rows have no non-causal instantiation of the two-wave tile
+    // (GENERAL_ONLY in launch_dq_nw), and the general one measured +6 % there against the one-wave pipelined form
+    if constexpr (bwd_ksplit<T, D, BIAS>()) {
+      if (p.causal) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
+    }
   }
   return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);
 }
 
-template <typename T, int D, bool BIAS, int NW, bool LEAN = false>
+template <typename T, int D, bool BIAS, int NW, bool LEAN = false, bool QSPLIT = false>
 static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
-  constexpr int BNK = 32 * NW;
+  constexpr int BNK = 32 * (QSPLIT ? NW / 2 : NW);
   // staged query tile: 32 rows for wide feature rows (16-bit D >= 96, f32 D >= 64: VGPR budget of the staging registers),
   // else 64; 128 in the 8-wave form (one workgroup per CU: the LDS is there, and half the barriers per key tile: -4.5%)
   // (the pipelined LDS-DMA form has no staging registers: wide rows can take deeper tiles too -> fragment prefetch across
@@ -1563,15 +1704,17 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr bool RING = kDkvRing && DMA_FORM && !LEAN && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0 &&
                         DkvLds<T, D, NW, BMQ, BIAS, LEAN, 3>::TOTAL <= ((NW == 8 || D * Traits<T>::ES > kDkv2WBytes) ? 160 : 80) * 1024;
   // NBUF x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
-  const size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN, RING ? 3 : 2>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
+  static_assert(!QSPLIT || RING, "query-split form needs the ring");
+  size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN, RING ? 3 : 2>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
+  if (QSPLIT && lds < (size_t)(NW / 2) * 64 * 16 * TileGeom<D, Traits<T>::ES>::DB * 8) lds = (size_t)(NW / 2) * 64 * 16 * TileGeom<D, Traits<T>::ES>::DB * 8;
   const dim3 grid((unsigned)(p.B * p.H * PT), (unsigned)(p.dkv_splits > 1 ? p.dkv_splits : 1));
   if (p.causal) {        // (two instantiations, see launch_fwd_nw)
-    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, false, RING>;
+    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, false, RING, QSPLIT>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
   } else {
-    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, true, RING>;
+    auto kern = bwd_dkv_kernel<T, D, NW, BMQ, BIAS, LEAN, true, RING, QSPLIT>;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
@@ -1584,6 +1727,11 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if (p.dkv_splits > 1) return launch_dkv_nw<T, D, BIAS, 4>(p, s);       // split-query path: 128-key tiles x query ranges
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
+    if constexpr (bwd_ksplit<T, D, BIAS>() && D == 64) {      // at most one 128-key workgroup per CU: its wave halves split the queries
+      const int KT4 = (p.M + 127) / 128;
+      // (from 512 queries: below, the four or fewer 128-row tiles of a pass do not pay for the hand-over -- 23.5 vs 24.7 us at N = 333 / 777)
+      if (p.N >= 512 && (int64_t)p.B * p.H * (p.causal ? (KT4 + 1) / 2 : KT4) <= 256) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);
+    }
   } else if constexpr (Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES <= 256) {
     // lean form (two waves per SIMD, V fragments from the LDS) where an 8-wave workgroup per CU still covers the chip; smaller grids
     // keep the one-wave pipelined form.  (Two 4-wave workgroups per CU would do as well, but a grid with >= 448 of those always has

@@ -1359,7 +1359,7 @@ template <typename T, int D, bool BIAS> constexpr bool fwd_ksplit() {
 template <typename T, int D>
 static bool use_ksplit_fwd(const FwdParams& p) {
   const int MT = (p.N + 127) / 128;
-  const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
+  const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT) * (p.splits > 1 ? p.splits : 1);
   if (D * Traits<T>::ES > 128) return true;
 #ifndef FCSA_KSPLIT_WGS
 #define FCSA_KSPLIT_WGS 256
@@ -1445,7 +1445,12 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
     }
     return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);
   }
-  if (p.splits > 1) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);   // split-key path: 128-row tiles x key ranges
+  if (p.splits > 1) {                                                   // split-key path: 128-row tiles x key ranges
+    if constexpr (fwd_ksplit<T, D, BIAS>()) {
+      if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, true, true>(p, s);
+    }
+    return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
+  }
   if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   } else if constexpr (fwd_lean<T, D, BIAS>()) {

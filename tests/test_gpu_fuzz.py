@@ -219,6 +219,15 @@ NAMED_CASES = [
     _named("K8_bf16_d64_one_row", groups=1, D=64, N=1, M=130, seed=208),
     _named("K9_bf16_d64_causal_n_gt_m", groups=1, D=64, N=400, M=130, causal=True, seed=209),
     _named("K10_f16_d128_two_tiles", dtype="f16", groups=4, D=128, N=333, M=128, seed=210),
+    # ... and the backward's forms: dQ key-split (same geometry as the forward), dK/dV query-split (from 512 queries: the wave halves take
+    # the first / second 64 rows of every staged 128-row tile): diagonal crossing either half, ragged last tile, masks, N != M
+    _named("K11_bf16_d64_qsplit_causal", groups=1, D=64, N=600, M=520, causal=True, B=2, H=2, seed=211),
+    _named("K12_f16_d64_qsplit_mask_ragged", dtype="f16", groups=1, D=64, N=1000, M=300, mask=True, seed=212),
+    _named("K13_bf16_d64_qsplit_causal_m_gt_n_single_kv", groups=1, D=64, N=520, M=1030, causal=True, single_kv=True, H=3, seed=213),
+    _named("K14_bf16_d64_qsplit_one_key_tile", groups=2, D=64, N=777, M=100, seed=214),
+    _named("K15_f16_d96_dq_ksplit_causal", dtype="f16", groups=1, D=96, N=300, M=300, causal=True, seed=215),
+    _named("K16_bf16_d128_dq_ksplit_causal", groups=1, D=128, N=520, M=260, causal=True, seed=216),
+    _named("K17_bf16_d64_qsplit_causal_n_gt_m", groups=1, D=64, N=700, M=130, causal=True, seed=217),
 ]
 
 
