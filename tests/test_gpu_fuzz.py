@@ -86,6 +86,31 @@ def _configs_long(n_cases=24, seed=20260927):
     return out
 
 
+def _configs_mid(n_cases=16, seed=20260928):
+    """Mid-size problems (at most one 128-row / 128-key workgroup per CU, N and M in the hundreds to low thousands): the forms whose wave
+    halves split the keys (forward, dQ) or the queries (dK/dV) are chosen by the normal dispatch (round 4), in random
+    combination with causal masking at any N - M, key masks, single-headed K/V, groups and the three head dims that have the forms."""
+    seed = int(os.environ.get("FCSA_FUZZ_SEED", seed))
+    rng = np.random.RandomState(seed + 2)
+    out = []
+    for c in range(n_cases):
+        dtype = rng.choice(["bf16", "f16", "f32"], p=[0.5, 0.4, 0.1])
+        D = int(rng.choice([32, 64, 96, 128], p=[0.1, 0.5, 0.15, 0.25]))
+        B, H = int(rng.randint(1, 4)), int(rng.randint(1, 7))
+        N = int(rng.randint(300, 1500))
+        M = N if rng.rand() < 0.4 else int(rng.randint(65, 1500))
+        mode = rng.choice(["none", "causal", "mask"], p=[0.3, 0.5, 0.2])
+        groups = int(rng.choice([g for g in (1, 2, 4, 8) if D % g == 0]))
+        l2 = rng.rand() < 0.9
+        scale = float(rng.choice([1, 8, 10]))
+        if scale * groups > 80:
+            scale = 8.0
+        out.append(dict(id=f"M{c:02d}", dtype=str(dtype), B=B, H=H, N=N, M=M, D=D, causal=mode == "causal", mask=mode == "mask",
+                        bias=False, bias_batch=False, single_kv=bool(rng.rand() < 0.25), groups=groups if l2 else 1, l2norm=bool(l2),
+                        scale=scale if l2 else 0.125, seed=int(rng.randint(1 << 30))))
+    return out
+
+
 def _npf(t):
     return t.detach().cpu().double().numpy()
 
@@ -178,7 +203,7 @@ def evaluate(cfg, raw=True):
             yield f"{pr}: {name} rel-L2", rel, lim
 
 
-@pytest.mark.parametrize("cfg", _configs() + _configs_long(), ids=lambda c: c["id"])
+@pytest.mark.parametrize("cfg", _configs() + _configs_long() + _configs_mid(), ids=lambda c: c["id"])
 def test_random_config_matches_oracle(cfg):
     for what, got, lim in evaluate(cfg):
         assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"
