@@ -253,7 +253,7 @@ template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false, int 
 // fwd_kernel, KSPLIT): for grids of at most one 128-row workgroup per CU, whose four waves would each have a SIMD to themselves.
 template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO, bool KM, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
-  static_assert(!KSPLIT || (NW == 8 && TWO && !BIAS && SUB == 2 && Traits<T>::ES == 2), "key-split form: 8 waves, two-wave tile, 16 bit, no bias, 2 tiles per stage");
+  static_assert(!KSPLIT || (NW == 8 && TWO && SUB == 2 && Traits<T>::ES == 2), "key-split form: 8 waves, two-wave tile, 16 bit, 2 tiles per stage");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -1136,7 +1136,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
 // the pass: the mirror image of the key-split forward / dQ forms, for grids of at most one 128-key workgroup per CU.
 template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM, bool RING = false, bool QSPLIT = false>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes || LEAN) ? 2 : 1)) bwd_dkv_kernel(const BwdParams p) {
-  static_assert(!QSPLIT || (NW == 8 && RING && !BIAS && !LEAN && BMQ % 64 == 0), "query-split form: 8 waves, pipelined ring tile");
+  static_assert(!QSPLIT || (NW == 8 && !LEAN && (RING || BIAS) && BMQ % 64 == 0), "query-split form: 8 waves; pipelined ring tile, or the generic tile with a bias");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -1331,7 +1331,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
     bias_col = slice;
     bias_blk = slice + (int64_t)nw * (int64_t)sizeof(typename TR::elem);
     bvec = n0 + BNK <= p.M && ((int64_t)p.M * TR::ES) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
-    if (bvec && t0 < QT) bb.request(bias_blk, min(t0 * BMQ + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
+    if (bvec && t0 < QT) bb.request(bias_blk, min(t0 * BMQ + hq + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
   }
   // (the first query tile is requested ahead of the K / V fragment loads -- or, with SEP, from the previous epilogue)
   if (!have_pre) request_ahead(pass);
@@ -1465,9 +1465,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
         if (!skip) dkv_tile<T, D, BMQ, MODE, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
                                                             bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32, NW == 8 && wave >= 4);
       } else {
-        const int next_i0 = more ? i0 + BMQ : -1;
+        const int next_i0 = more ? i0 + hq + BMQ : -1;      // (QSPLIT: of this wave's rows of the next staged tile)
         if (!skip) {
-          dkv_tile<T, D, BMQ, MODE, BIAS>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, bias_col, ts, bb, bscr,
+          dkv_tile<T, D, BMS, MODE, BIAS>(cur + hoff, cur + TILE_B + hoff, lcs + hq, dls + hq, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0 + hq, diff, bias_col, ts, bb, bscr,
                                             bias_blk, bvec, next_i0, lane);
         } else if constexpr (BIAS) {      // the block requested for this tile is not used: request the next tile's first block instead
           if (bvec && more) bb.request(bias_blk, min(next_i0 + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);
@@ -1668,7 +1668,10 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges (the key-split form measured level there)
   if constexpr (NARROW) {
     if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
-    if constexpr (bwd_ksplit<T, D, BIAS>()) {      // at most one 128-row workgroup per CU: its wave halves split the keys
+#ifndef FCSA_DQ_KSPLIT_BIAS
+#define FCSA_DQ_KSPLIT_BIAS 1
+#endif
+    if constexpr (bwd_ksplit<T, D, false>() && (!BIAS || FCSA_DQ_KSPLIT_BIAS != 0)) {      // at most one 128-row workgroup per CU: its wave halves split the keys
       const int MT4 = (p.N + 127) / 128;
       if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= 256) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
     }
@@ -1704,7 +1707,7 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
   constexpr bool RING = kDkvRing && DMA_FORM && !LEAN && (BMQ * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0 &&
                         DkvLds<T, D, NW, BMQ, BIAS, LEAN, 3>::TOTAL <= ((NW == 8 || D * Traits<T>::ES > kDkv2WBytes) ? 160 : 80) * 1024;
   // NBUF x [Q tile | dO tile | lc | -delta], epilogue scratch behind or inside them; bias launches: + the waves' transposition scratch
-  static_assert(!QSPLIT || RING, "query-split form needs the ring");
+  static_assert(!QSPLIT || RING || BIAS, "query-split form: ring tile, or the generic tile with a bias");
   size_t lds = DkvLds<T, D, NW, BMQ, BIAS, LEAN, RING ? 3 : 2>::TOTAL + (BIAS ? (size_t)NW * BiasBlock<T>::BYTES : 0);
   if (QSPLIT && lds < (size_t)(NW / 2) * 64 * 16 * TileGeom<D, Traits<T>::ES>::DB * 8) lds = (size_t)(NW / 2) * 64 * 16 * TileGeom<D, Traits<T>::ES>::DB * 8;
   const dim3 grid((unsigned)(p.B * p.H * PT), (unsigned)(p.dkv_splits > 1 ? p.dkv_splits : 1));
@@ -1727,7 +1730,10 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if (p.dkv_splits > 1) return launch_dkv_nw<T, D, BIAS, 4>(p, s);       // split-query path: 128-key tiles x query ranges
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
-    if constexpr (bwd_ksplit<T, D, BIAS>() && D == 64) {      // at most one 128-key workgroup per CU: its wave halves split the queries
+#ifndef FCSA_DKV_QSPLIT_BIAS
+#define FCSA_DKV_QSPLIT_BIAS 1
+#endif
+    if constexpr (bwd_ksplit<T, D, false>() && D == 64 && (!BIAS || FCSA_DKV_QSPLIT_BIAS != 0)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
       const int KT4 = (p.M + 127) / 128;
       // (from 512 queries: below, the four or fewer 128-row tiles of a pass do not pay for the hand-over -- 23.5 vs 24.7 us at N = 333 / 777)
       if (p.N >= 512 && (int64_t)p.B * p.H * (p.causal ? (KT4 + 1) / 2 : KT4) <= 256) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);

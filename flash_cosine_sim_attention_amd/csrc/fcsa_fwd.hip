@@ -567,7 +567,7 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 // lean form does not prefetch.
 template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN, bool KM, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
-  static_assert(!KSPLIT || (NW == 8 && LEAN && !DYN && !BIAS && Traits<T>::ES == 2), "key-split form: 8 waves, lean tile, 16 bit, static shift, no bias");
+  static_assert(!KSPLIT || (NW == 8 && (LEAN != BIAS) && !DYN && Traits<T>::ES == 2), "key-split form: 8 waves, 16 bit, static shift; lean tile, or the generic tile with a bias");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -896,6 +896,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         mid();
         return;
       }
+      if constexpr (!LEAN) request_k(buf + half * TILE_B);      // (bias form: the generic tile takes its K fragments from registers; nothing is prefetched across stages)
       fwd_tile<T, D, MODE, BIAS, LEAN, DYN>(buf + (SUB + half) * TILE_B, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid,
                                            nullptr, false, buf + half * TILE_B);
     };
@@ -1353,8 +1354,12 @@ static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
 #ifndef FCSA_FWD_KSPLIT
 #define FCSA_FWD_KSPLIT 1
 #endif
+#ifndef FCSA_FWD_KSPLIT_BIAS
+#define FCSA_FWD_KSPLIT_BIAS 1
+#endif
 template <typename T, int D, bool BIAS> constexpr bool fwd_ksplit() {
-  return FCSA_FWD_KSPLIT != 0 && Traits<T>::ES == 2 && !BIAS && (D == 64 || D == 96 || D == 128) && (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
+  return FCSA_FWD_KSPLIT != 0 && Traits<T>::ES == 2 && (BIAS ? (FCSA_FWD_KSPLIT_BIAS != 0 && D == 64) : (D == 64 || D == 96 || D == 128)) &&
+         (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
 }
 template <typename T, int D>
 static bool use_ksplit_fwd(const FwdParams& p) {
@@ -1447,7 +1452,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   }
   if (p.splits > 1) {                                                   // split-key path: 128-row tiles x key ranges
     if constexpr (fwd_ksplit<T, D, BIAS>()) {
-      if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, true, true>(p, s);
+      if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, !BIAS, true>(p, s);
     }
     return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
   }
@@ -1458,7 +1463,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
   }
   if constexpr (fwd_ksplit<T, D, BIAS>()) {
-    if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, true, true>(p, s);
+    if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, !BIAS, true>(p, s);
   }
   return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
 }

@@ -253,6 +253,11 @@ NAMED_CASES = [
     _named("K15_f16_d96_dq_ksplit_causal", dtype="f16", groups=1, D=96, N=300, M=300, causal=True, seed=215),
     _named("K16_bf16_d128_dq_ksplit_causal", groups=1, D=128, N=520, M=260, causal=True, seed=216),
     _named("K17_bf16_d64_qsplit_causal_n_gt_m", groups=1, D=64, N=700, M=130, causal=True, seed=217),
+    # ... with a learned bias (forward: generic tile on the split form; dQ: two-wave tile; dK/dV: generic tile with the LDS-transposed bias blocks)
+    _named("K18_bf16_d64_bias_causal", groups=1, D=64, N=600, M=704, causal=True, bias=True, B=2, H=2, seed=218),
+    _named("K19_f16_d64_bias_batch_mask", dtype="f16", groups=1, D=64, N=1024, M=520, mask=True, bias=True, bias_batch=True, B=2, H=3, seed=219),
+    _named("K20_bf16_d64_bias_ragged", groups=2, D=64, N=515, M=333, bias=True, seed=220),
+    _named("K21_bf16_d64_bias_small", groups=1, D=64, N=100, M=257, bias=True, causal=True, seed=221),
 ]
 
 
