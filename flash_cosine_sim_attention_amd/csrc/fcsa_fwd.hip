@@ -567,7 +567,7 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 // lean form does not prefetch.
 template <typename T, int D, int NW, bool BIAS, bool DYN, bool LEAN, bool KM, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ? 2 : 1)) fwd_kernel(const FwdParams p) {
-  static_assert(!KSPLIT || (NW == 8 && (LEAN != BIAS) && !DYN && Traits<T>::ES == 2), "key-split form: 8 waves, 16 bit, static shift; lean tile, or the generic tile with a bias");
+  static_assert(!KSPLIT || (NW == 8 && (LEAN != BIAS) && Traits<T>::ES == 2), "key-split form: 8 waves, 16 bit; lean tile, or the generic tile with a bias");
   const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
@@ -919,7 +919,9 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   if constexpr (KSPLIT) {
     // the odd-tile half hands its partials to the even-tile half of the same rows through the LDS (the staging buffers are free:
     // every wave's last LDS read came before the last stage barrier); 16-byte accesses, lane-contiguous
-    constexpr int NV = G::DB * 4 + 1;                                  // f32x4 per lane: O^T accumulators + (l, -, -, -)
+    // DYN: the halves kept their own per-row exponent references (c2row; a half that met no valid key has rmax == -inf and nothing
+    // accumulated): the partials are brought to the larger reference before they are added -- the one rescale a running max costs here
+    constexpr int NV = G::DB * 4 + 1;                                  // f32x4 per lane: O^T accumulators + (l, reference, valid, -)
     f32x4* ms = reinterpret_cast<f32x4*>(smem) + rwave * (NV * 64) + lane;
     if (half == 1) {
 #pragma unroll
@@ -929,20 +931,30 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
           const f32x4 v = {o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
           ms[(db * 4 + g) * 64] = v;
         }
-      const f32x4 lv = {lt, 0.f, 0.f, 0.f};
+      const f32x4 lv = {lt, c2row, rmax == -INFINITY ? 0.f : 1.f, 0.f};
       ms[(NV - 1) * 64] = lv;
     }
     __syncthreads();
     if (half == 0) {
+      const f32x4 lv = ms[(NV - 1) * 64];
+      float f0 = 1.f, f1 = 1.f;
+      if constexpr (DYN) {
+        const bool v0 = rmax != -INFINITY, v1 = lv[2] != 0.f;
+        const float m = v0 ? (v1 ? fmaxf(c2row, lv[1]) : c2row) : lv[1];
+        f0 = v0 ? fast_exp2(c2row - m) : 0.f;
+        f1 = v1 ? fast_exp2(lv[1] - m) : 0.f;
+        c2row = m;
+        if (v1) rmax = 0.f;      // (only its -inf-ness is read below)
+      }
 #pragma unroll
       for (int db = 0; db < G::DB; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = ms[(db * 4 + g) * 64];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[db][4 * g + e] += v[e];
+          for (int e = 0; e < 4; ++e) o[db][4 * g + e] = DYN ? o[db][4 * g + e] * f0 + v[e] * f1 : o[db][4 * g + e] + v[e];
         }
-      lt += ms[(NV - 1) * 64][0];
+      lt = DYN ? lt * f0 + lv[0] * f1 : lt + lv[0];
     }
     __syncthreads();                                                    // (the row epilogue's scratch overlays what was just read)
     if (half == 1) {
@@ -1447,6 +1459,9 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
       if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
     } else if constexpr (fwd_lean<T, D, BIAS>()) {
       if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true, true>(p, s);
+    }
+    if constexpr (fwd_ksplit<T, D, BIAS>()) {
+      if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, true, !BIAS, true>(p, s);
     }
     return launch_fwd_nw<T, D, BIAS, 4, true>(p, s);
   }

@@ -258,6 +258,11 @@ NAMED_CASES = [
     _named("K19_f16_d64_bias_batch_mask", dtype="f16", groups=1, D=64, N=1024, M=520, mask=True, bias=True, bias_batch=True, B=2, H=3, seed=219),
     _named("K20_bf16_d64_bias_ragged", groups=2, D=64, N=515, M=333, bias=True, seed=220),
     _named("K21_bf16_d64_bias_small", groups=1, D=64, N=100, M=257, bias=True, causal=True, seed=221),
+    # ... with the online per-row exponent reference: the halves keep their own references and meet at the larger one when they add their partials
+    _named("K22_f16_d64_online_causal", dtype="f16", groups=1, scale=16.0, D=64, N=600, M=600, causal=True, B=2, H=2, seed=222),
+    _named("K23_bf16_d128_online_bound96", groups=8, scale=12.0, D=128, N=520, M=390, seed=223),
+    _named("K24_f16_d64_online_mask_one_tile_each", dtype="f16", groups=2, scale=8.0, D=64, N=200, M=128, mask=True, seed=224),
+    _named("K25_f16_d96_online_causal_m_gt_n", dtype="f16", groups=1, scale=16.0, D=96, N=300, M=450, causal=True, seed=225),
 ]
 
 
