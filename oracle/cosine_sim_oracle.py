@@ -281,7 +281,7 @@ def tiled_attention(q, k, v, mask=None, attn_bias=None, scale=8, causal=False,
 # ----------------------------------------------------------------------------
 
 def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
-                       l2norm_qk=True, attn_bias_batch_dim=False, dtype=np.float64, eps=1e-10, operand_dtype=None):
+                       l2norm_qk=True, attn_bias_batch_dim=False, dtype=np.float64, eps=1e-10, operand_dtype=None, o_saved=None):
     """Analytic gradients (dq, dk, dv, d_bias) w.r.t. the RAW q, k, v, bias.
 
     Kernel math (w.r.t. the normalised qh, kh):
@@ -321,7 +321,13 @@ def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1
     inv_l = 1.0 / np.maximum(l, eps)
     p = pt * inv_l[..., None]
     o = np.einsum("bhij,bhjd->bhid", p, vb)
-    delta = (do * o).sum(-1)
+    # o_saved: `o` is an INPUT of the backward (reference backward(..., o, do, ...): delta is taken from the stored output,
+    # backward_preprocess cu:1256-1335).  Given, delta uses it instead of the exact output: the gradient a backward pass computes from
+    # THAT saved tensor.  It matters where a row's weight sits on one or two keys: dP - delta cancels, and the rounding of a 16-bit `o`
+    # is what is left -- 0.5 ... 8 % of dq / dk / d_bias on a single-row problem (exploratory fuzz seed 5, case X11 of tests/test_gpu_fuzz.py),
+    # the same in every implementation that keeps `o` in 16 bits.
+    o_used = o if o_saved is None else np.asarray(o_saved, dtype=dtype).reshape(o.shape)
+    delta = (do * o_used).sum(-1)
     dv = np.einsum("bhij,bhid->bhjd", p, do)
     dp = np.einsum("bhid,bhjd->bhij", do, vb)
     ds = p * (dp - delta[..., None])

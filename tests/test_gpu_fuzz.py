@@ -178,7 +178,8 @@ def evaluate(cfg, raw=True):
             # operand-faithful twin: exact arithmetic on the 16-bit operands, FIXED bars at every logit range
             ro, _ = O.attention_forward_stats(_npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], **okw)
             yield f"{pr}: forward excess (16-bit operands)", (np.abs(got - ro) - rtol * np.abs(ro)).max(), atol * max(vmax, 1.0)
-            grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], **okw)
+            # (the backward's own input `o`: delta = rowsum(dO * o) is taken from the output the forward stored, oracle `o_saved`)
+            grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], o_saved=got, **okw)
             for name, gg, rr in zip(names, gots, grads):
                 rel = np.linalg.norm(gg - rr) / max(np.linalg.norm(rr), 1e-3 * np.sqrt(rr.size))
                 yield f"{pr}: {name} rel-L2 (16-bit operands)", rel, GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
@@ -232,6 +233,11 @@ NAMED_CASES = [
     _named("X8_bf16_bound70_bias_takes_online", groups=8, scale=8.75, D=64, N=100, M=140, bias=True, seed=108),
     _named("X9_bf16_bound96_online", groups=8, scale=12.0, D=128, N=257, M=257, causal=True, seed=109),
     _named("X10_bf16_long_n_short_m_groups_mask", B=1, H=2, groups=2, scale=8.0, D=64, N=2500, M=200, mask=True, seed=110),
+    # round 4, exploratory seed 5: ONE query row whose weight sits on a key or two (scale * groups = 32 plus a bias): dP - delta cancels and
+    # what is left is the rounding of the stored 16-bit output delta is taken from (oracle: faithful delta) -- 3.0e-2 on dq / dk / d_bias
+    # against exact math, identical with and without round 4's split forms; and a two-feature-groups problem of three keys
+    _named("X11_bf16_single_row_concentrated_bias", B=1, H=1, groups=2, scale=16.0, D=64, N=1, M=3521, bias=True, bias_batch=True, seed=673907546),
+    _named("X12_bf16_two_feature_groups_three_keys", B=2, H=3, groups=8, scale=8.0, D=16, N=1733, M=3, seed=230507859),
     # the key-split forward (fcsa_fwd.hip, KSPLIT: two wave halves take the even / odd 64-key tile of a stage): one tile only (the odd
     # half idles), odd and even tile counts, ragged tails, diagonal tiles in either half, key masks, every head dim that has the form
     _named("K1_bf16_d64_one_tile", groups=1, D=64, N=128, M=64, seed=201),

@@ -5,6 +5,7 @@ usage: fuzz_case.py "<python dict as printed by the failing assert>"  [more dict
 import ast, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))      # `cases` (tests/conftest.py does this under pytest)
 from tests.test_gpu_fuzz import evaluate
 
 for text in sys.argv[1:]:
