@@ -1620,10 +1620,16 @@ namespace fcsa {
 #define FCSA_BWD_KSPLIT 1
 #endif
 template <typename T, int D, bool BIAS> constexpr bool bwd_ksplit() {
+#ifndef FCSA_KSPLIT_D32
+#define FCSA_KSPLIT_D32 32      // (0: not at D = 32)
+#endif
+#ifndef FCSA_KSPLIT_D16
+#define FCSA_KSPLIT_D16 16      // (0: not at D = 16)
+#endif
 #ifndef FCSA_BWD_KSPLIT_WIDE
 #define FCSA_BWD_KSPLIT_WIDE 1
 #endif
-  return FCSA_BWD_KSPLIT != 0 && Traits<T>::ES == 2 && !BIAS && (D == 64 || (FCSA_BWD_KSPLIT_WIDE != 0 && (D == 96 || D == 128)));
+  return FCSA_BWD_KSPLIT != 0 && Traits<T>::ES == 2 && !BIAS && (D == 64 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16 || (FCSA_BWD_KSPLIT_WIDE != 0 && (D == 96 || D == 128)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1733,7 +1739,7 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
 #ifndef FCSA_DKV_QSPLIT_BIAS
 #define FCSA_DKV_QSPLIT_BIAS 1
 #endif
-    if constexpr (bwd_ksplit<T, D, false>() && D == 64 && (!BIAS || FCSA_DKV_QSPLIT_BIAS != 0)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
+    if constexpr (bwd_ksplit<T, D, false>() && (D == 64 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16) && (!BIAS || FCSA_DKV_QSPLIT_BIAS != 0)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
       const int KT4 = (p.M + 127) / 128;
       // (from 512 queries: below, the four or fewer 128-row tiles of a pass do not pay for the hand-over -- 23.5 vs 24.7 us at N = 333 / 777)
       if (p.N >= 512 && (int64_t)p.B * p.H * (p.causal ? (KT4 + 1) / 2 : KT4) <= 256) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);

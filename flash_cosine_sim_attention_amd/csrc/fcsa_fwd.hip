@@ -1366,11 +1366,17 @@ static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
 #ifndef FCSA_FWD_KSPLIT
 #define FCSA_FWD_KSPLIT 1
 #endif
+#ifndef FCSA_KSPLIT_D32
+#define FCSA_KSPLIT_D32 32      // (0: not at D = 32)
+#endif
+#ifndef FCSA_KSPLIT_D16
+#define FCSA_KSPLIT_D16 16      // (0: not at D = 16)
+#endif
 #ifndef FCSA_FWD_KSPLIT_BIAS
 #define FCSA_FWD_KSPLIT_BIAS 1
 #endif
 template <typename T, int D, bool BIAS> constexpr bool fwd_ksplit() {
-  return FCSA_FWD_KSPLIT != 0 && Traits<T>::ES == 2 && (BIAS ? (FCSA_FWD_KSPLIT_BIAS != 0 && D == 64) : (D == 64 || D == 96 || D == 128)) &&
+  return FCSA_FWD_KSPLIT != 0 && Traits<T>::ES == 2 && (BIAS ? (FCSA_FWD_KSPLIT_BIAS != 0 && (D == 64 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16)) : (D == 64 || D == 96 || D == 128 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16)) &&
          (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
 }
 template <typename T, int D>

@@ -269,6 +269,11 @@ NAMED_CASES = [
     _named("K23_bf16_d128_online_bound96", groups=8, scale=12.0, D=128, N=520, M=390, seed=223),
     _named("K24_f16_d64_online_mask_one_tile_each", dtype="f16", groups=2, scale=8.0, D=64, N=200, M=128, mask=True, seed=224),
     _named("K25_f16_d96_online_causal_m_gt_n", dtype="f16", groups=1, scale=16.0, D=96, N=300, M=450, causal=True, seed=225),
+    # ... and at the narrow head dims (one 16-byte chunk pair per row at D = 16: a single k-step per chain)
+    _named("K26_bf16_d32_causal", groups=1, D=32, N=777, M=777, causal=True, B=2, H=2, seed=226),
+    _named("K27_f16_d32_bias_mask", dtype="f16", groups=2, D=32, N=600, M=330, mask=True, bias=True, seed=227),
+    _named("K28_bf16_d16_causal_m_gt_n", groups=1, D=16, N=520, M=700, causal=True, seed=228),
+    _named("K29_f16_d16_online_ragged", dtype="f16", groups=2, scale=8.0, D=16, N=1000, M=129, seed=229),
 ]
 
 
