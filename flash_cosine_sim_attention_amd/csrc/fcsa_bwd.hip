@@ -254,7 +254,9 @@ template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false, int 
 template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO, bool KM, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const BwdParams p) {
   static_assert(!KSPLIT || (NW == 8 && TWO && SUB == 2 && Traits<T>::ES == 2), "key-split form: 8 waves, two-wave tile, 16 bit, 2 tiles per stage");
-  const int causal = KM ? 0 : p.causal;      // (same type and value as p.causal: the causal instantiations compile to what they were)
+  // (same type and value as p.causal: the causal instantiations compile to what they were.  The key-split form's !KM twin is only ever
+  //  launched causal -- launch_dq_b -- and says so: at 256-byte rows the kernel sits at its 256 registers)
+  const int causal = KM ? 0 : KSPLIT ? 1 : p.causal;
   typedef TileGeom<D, Traits<T>::ES> G;
   typedef Traits<T> TR;
   constexpr int RWAVES = KSPLIT ? NW / 2 : NW;      // waves that own distinct row slices
