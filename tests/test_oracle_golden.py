@@ -159,3 +159,37 @@ def test_tiled_cpu_port_matches_numpy_oracle():
     o = P.tiled_forward_cpu(q, k1, v1, mask=mask, groups=2, scale=4.0, row_tile=64, col_tile=32)
     ref = O.plain_attention(q.double().numpy(), k1.double().numpy(), v1.double().numpy(), mask=mask.numpy(), groups=2, scale=4.0)
     assert np.abs(o.double().numpy() - ref).max() < 2e-5
+
+
+def test_backward_o_saved_is_the_backward_input():
+    """`o` is an input of the backward (reference backward_preprocess, cu:1256-1335: delta = rowsum(dO * o)).  With the exact output the
+    option changes nothing; with a perturbed one the gradients move exactly as the analytic dependence on delta says: dS changes by
+    -P * d(delta), so dv (which does not depend on delta) stays, and dq / dk change by the corresponding products."""
+    rng = np.random.RandomState(7)
+    b, h, n, m, d = 2, 2, 5, 9, 16
+    q, k, v, do = (rng.randn(b, h, x, d) for x in (n, m, m, n))
+    kw = dict(scale=8, groups=2, causal=True)
+    o, _ = O.attention_forward_stats(q, k, v, **kw)
+    base = O.attention_backward(do, q, k, v, **kw)
+    same = O.attention_backward(do, q, k, v, o_saved=o, **kw)
+    for a, c in zip(base[:3], same[:3]):
+        np.testing.assert_allclose(a, c, rtol=0, atol=1e-12)
+    o2 = o + 1e-3 * rng.randn(*o.shape)
+    moved = O.attention_backward(do, q, k, v, o_saved=o2, **kw)
+    np.testing.assert_allclose(moved[2], base[2], rtol=0, atol=1e-12)          # dv: no delta in it
+    assert np.abs(moved[0] - base[0]).max() > 1e-6                            # dq, dk follow delta
+    assert np.abs(moved[1] - base[1]).max() > 1e-6
+    # first-order check through the normalised operands: l2norm_qk = False makes dq^ = scale * dS K^ directly
+    qh, kh = O.l2norm(q, 1), O.l2norm(k, 1)
+    kw2 = dict(scale=8, groups=1, causal=True, l2norm_qk=False)
+    o3, st = O.attention_forward_stats(qh, kh, v, **kw2)
+    g0 = O.attention_backward(do, qh, kh, v, **kw2)
+    g1 = O.attention_backward(do, qh, kh, v, o_saved=o3 + 1e-3, **kw2)
+    ddelta = (do * 1e-3).sum(-1)                                               # delta moves by rowsum(dO) * 1e-3
+    # P from the forward statistics: dq^ changes by -scale * (P * ddelta) K^ = -scale * ddelta * (P K^)
+    s = np.einsum("bhid,bhjd->bhij", qh, kh) * 8
+    valid = np.tril(np.ones((n, m), dtype=bool), k=m - n)
+    p = np.where(valid, np.exp(s - 8), 0.0)
+    p = p / np.maximum(p.sum(-1, keepdims=True), 1e-10)
+    expect = -8 * ddelta[..., None] * np.einsum("bhij,bhjd->bhid", p, kh)
+    np.testing.assert_allclose(g1[0] - g0[0], expect, rtol=1e-9, atol=1e-12)
