@@ -248,7 +248,7 @@ template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN = false, int 
 // The phase trace showed the waves of this kernel waiting 25 % of their time at the per-tile barrier; one barrier per 128 keys
 // halves that (the same change gave the dKV kernel 4.5 %), one per 256 keys (LDS-DMA staging: no staging registers) another 1.2 %.
 // KM: the launch is not causal; tiles that need masking take the rank-1 form (see fwd_kernel)
-// KSPLIT (8 waves, the two-wave tile, SUB = 2): the workgroup owns 128 query rows and its wave halves split the KEYS -- waves 0-3 take
+// KSPLIT (8 waves, the two-wave tile with or without a bias, SUB = 2): the workgroup owns 128 query rows and its wave halves split the KEYS -- waves 0-3 take
 // the even 64-key tile of a stage, waves 4-7 the odd one -- and add their dQ partials through the LDS at the end of the pass (see
 // fwd_kernel, KSPLIT): for grids of at most one 128-row workgroup per CU, whose four waves would each have a SIMD to themselves.
 template <typename T, int D, int NW, bool BIAS, int SUB, bool TWO, bool KM, bool KSPLIT = false>
@@ -1133,7 +1133,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
 }
 
 // RING: three staging buffers instead of two and the tile pipeline crosses the tile barrier (dkv_tile_pipe); pipelined LDS-DMA form only
-// QSPLIT (8 waves, ring form): the workgroup owns 128 keys and its wave halves split the QUERIES of every staged tile -- waves 0-3 take its
+// QSPLIT (8 waves; the pipelined ring tile, or the generic two-buffer tile where a bias rides along): the workgroup owns 128 keys and its wave halves split the QUERIES of every staged tile -- waves 0-3 take its
 // first BMQ / 2 rows, waves 4-7 the others, for the same four 32-key slices -- and add their dK / dV partials through the LDS at the end of
 // the pass: the mirror image of the key-split forward / dQ forms, for grids of at most one 128-key workgroup per CU.
 template <typename T, int D, int NW, int BMQ, bool BIAS, bool LEAN, bool KM, bool RING = false, bool QSPLIT = false>      // KM: not causal, masked tiles in the rank-1 form (see fwd_kernel)

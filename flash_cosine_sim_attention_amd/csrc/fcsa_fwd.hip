@@ -559,9 +559,10 @@ template <typename T, int D, bool DYN> constexpr int fwd_stage_tiles() {
 // start from -reference instead of the static shift and inv_l is saved as log2(1 / sum_j exp(S_ij)), i.e. for shift 0.
 // KM: the launch is NOT causal (compile-time: a third tile loop in one kernel made hipcc spill 200 registers): tiles that need
 // masking -- a key mask, the ragged last tile -- take the rank-1 MFMA form (fwd_tile MODE 2) instead of the per-logit select.
-// KSPLIT (8 waves, lean tile form): the workgroup owns 128 query rows and its two wave halves split the KEYS -- a stage is two 64-key
+// KSPLIT (8 waves; the lean tile, or the generic tile where a bias rides along; static or online exponent reference): the workgroup
+// owns 128 query rows and its two wave halves split the KEYS -- a stage is two 64-key
 // tiles, waves 0-3 take the even tile, waves 4-7 the odd one, for the same four 32-row slices -- and add their (O, l) partials through
-// the LDS at the end of the pass (plain sums: there is no running max to reconcile).  For grids whose 128-row workgroups cannot give
+// the LDS at the end of the pass (plain sums; with the online reference the halves first meet at the larger one).  For grids whose 128-row workgroups cannot give
 // every SIMD two waves: 256 four-wave workgroups (C2: 4 x 8 x 1024 rows; C5 at D = 128, where the four-wave form runs ONE wave per
 // SIMD whatever the grid) are one wave per SIMD; this form keeps the grid and doubles the waves, and the partner wave hides what the
 // lean form does not prefetch.
