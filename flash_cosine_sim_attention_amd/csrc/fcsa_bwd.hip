@@ -43,26 +43,11 @@ constexpr int kDq2WBytes = 128;      // row bytes D*ES up to which the dQ kernel
 // of what the same kernel reaches at D = 64; smaller grids still do (a lone wave is better off with the pipelined tile).
 template <typename T, int D> constexpr bool dq_can_two_waves() { return D * Traits<T>::ES <= (Traits<T>::ES == 2 ? 256 : 128); }
 constexpr int kDkv2WBytes = 128;     // same for the dKV kernel
-#ifndef FCSA_DQ_SUB8
-#define FCSA_DQ_SUB8 4
-#endif
-#ifndef FCSA_DKV_BMQ8
-#define FCSA_DKV_BMQ8 128
-#endif
-#ifndef FCSA_PRIO_BLOCKS
-#define FCSA_PRIO_BLOCKS 0      // 0: half of the interval's blocks
-#endif
-constexpr int kDqSub8 = FCSA_DQ_SUB8;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
-#ifndef FCSA_DQ_SPLIT0
-#define FCSA_DQ_SPLIT0 1
-#endif
-constexpr bool kDqSplitFirstStage = FCSA_DQ_SPLIT0 != 0;      // cold first stage of a dQ pass requested in two parts (bwd_dq_kernel, SPLIT0)
-constexpr int kDkvBmq8 = FCSA_DKV_BMQ8;        // staged query rows of the 8-wave dKV kernel
+constexpr int kDqSub8 = 4;           // 64-key tiles per LDS stage of the 8-wave dQ kernel (16 bit): one barrier per 256 keys
+constexpr bool kDqSplitFirstStage = true;      // cold first stage of a dQ pass requested in two parts (bwd_dq_kernel, SPLIT0)
+constexpr int kDkvBmq8 = 128;        // staged query rows of the 8-wave dKV kernel
 constexpr int kDkvBmqWide = 64;      // staged query rows of the dKV kernel for 16-bit D >= 96 (LDS-DMA form)
-#ifndef FCSA_DKV_RING
-#define FCSA_DKV_RING 1
-#endif
-constexpr bool kDkvRing = FCSA_DKV_RING != 0;
+constexpr bool kDkvRing = true;
       // three-buffer ring + tile pipeline across the tile barrier (dkv_tile_pipe)
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_dkv[128];
@@ -352,6 +337,11 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   // pass's epilogue is not split: its flight is covered.)
   // (not with a bias: its loads inside the tile would be younger than the stage pieces the counted wait must leave in flight)
   constexpr bool SPLIT0 = !KSPLIT && DMA && !BIAS && SUB > 1 && DS::PER == SUB && (NW * 1024) / G::ROWB == BN && kDqSplitFirstStage;
+  // The counted wait below (vmcnt(2 * PER)) publishes tiles 1.. of the cold stage only if (a) no VM load / store is issued between the
+  // stage-1 DMA requests and the wait, and (b) tile 0 reads nothing but its own LDS tile.  Both hold for the two-wave tile without a
+  // bias (dq_tile<.., TWO>: LDS reads and MFMAs only); the pipelined one-wave tile prefetches the NEXT tile's fragments and must not
+  // be combined with it.
+  static_assert(!SPLIT0 || (TWO && !BIAS), "SPLIT0's counted vmcnt needs a tile body without VM operations or next-tile LDS reads");
   bool split0 = false;
   auto request_ahead = [&](int b_, int h_, int pass_, bool cold) {
     int m0_, nt_;
@@ -550,10 +540,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
         if (sub == 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
         if (sub == SUB / 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
       }
-#ifndef FCSA_DQ_PIPE_ALL
-#define FCSA_DQ_PIPE_ALL 0
-#endif
-      if constexpr (TR::ES == 2 && !BIAS && (!TWO || FCSA_DQ_PIPE_ALL)) {      // pipelined tile: one wave per SIMD only
+      if constexpr (TR::ES == 2 && !BIAS && !TWO) {      // pipelined tile: one wave per SIMD only
         bool skip = false;
         if constexpr (MASKED) skip = causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
@@ -574,6 +561,9 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
         }
       }
       if (last_of_stage) {                                 // workgroup-uniform
+        // (a ragged last stage, or a causal pass that ends early, can leave the younger half at priority 1: drop it before the merge /
+        //  epilogue / next prologue, where the older half does the stores)
+        if constexpr (kPrioBwd == 1 && NW == 8 && SUB >= 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); }
         if (more) {
           if constexpr (DMA) {
             dma_wait();
@@ -1062,7 +1052,7 @@ FCSA_DEV void dkv_tile_pipe(const char* qt, const char* dot, const float* lcs, c
     FCSA_FENCE();
     if constexpr (kPrioBwd == 1) {      // (`young` is wave-uniform and lives in an SGPR: a scalar branch around one s_setprio)
       if (ib == 0) { if (young) __builtin_amdgcn_s_setprio(1); }
-      if (ib == (FCSA_PRIO_BLOCKS ? FCSA_PRIO_BLOCKS : NB / 2)) { if (young) __builtin_amdgcn_s_setprio(0); }
+      if (ib == NB / 2) { if (young) __builtin_amdgcn_s_setprio(0); }
     }
     if (ib == 1) FCSA_STAMP(ts, 2);
     // ---- M1: S = Q K^T + lc, dP = dO V^T - delta (the per-query terms are the accumulators' initial values)
@@ -1618,27 +1608,15 @@ namespace fcsa {
 #endif
 
 // key-split forms of the backward kernels (bwd_dq_kernel<.., KSPLIT>): 16-bit, no bias, the head dims the forward has it for
-#ifndef FCSA_BWD_KSPLIT
-#define FCSA_BWD_KSPLIT 1
-#endif
 template <typename T, int D, bool BIAS> constexpr bool bwd_ksplit() {
-#ifndef FCSA_KSPLIT_D32
-#define FCSA_KSPLIT_D32 32      // (0: not at D = 32)
-#endif
-#ifndef FCSA_KSPLIT_D16
-#define FCSA_KSPLIT_D16 16      // (0: not at D = 16)
-#endif
-#ifndef FCSA_BWD_KSPLIT_WIDE
-#define FCSA_BWD_KSPLIT_WIDE 1
-#endif
-  return FCSA_BWD_KSPLIT != 0 && Traits<T>::ES == 2 && !BIAS && (D == 64 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16 || (FCSA_BWD_KSPLIT_WIDE != 0 && (D == 96 || D == 128)));
+  return Traits<T>::ES == 2 && !BIAS && (D == 16 || D == 32 || D == 64 || D == 96 || D == 128);
 }
 
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
 static int tile_waves(int64_t batch_heads, int len, bool causal) {
   const int MT = (len + 255) / 256;
-  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
+  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8 ? 8 : 4;
 }
 
 template <typename T, int D, bool BIAS, int NW, bool TWO, bool KSPLIT = false>
@@ -1676,18 +1654,15 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges (the key-split form measured level there)
   if constexpr (NARROW) {
     if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
-#ifndef FCSA_DQ_KSPLIT_BIAS
-#define FCSA_DQ_KSPLIT_BIAS 1
-#endif
-    if constexpr (bwd_ksplit<T, D, false>() && (!BIAS || FCSA_DQ_KSPLIT_BIAS != 0)) {      // at most one 128-row workgroup per CU: its wave halves split the keys
+    if constexpr (bwd_ksplit<T, D, false>()) {      // at most one 128-row workgroup per CU: its wave halves split the keys
       const int MT4 = (p.N + 127) / 128;
-      if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= 256) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
+      if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= cu_count()) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
     }
   } else if constexpr (dq_can_two_waves<T, D>() && !BIAS) {
     // two waves per SIMD need two 128-row workgroups on every CU; smaller grids keep the one-wave (pipelined) form
     // (bias launches keep the one-wave form too: their two-wave instantiation spills 17 registers and was never measured ahead)
     const int MT4 = (p.N + 127) / 128;
-    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= 448) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
+    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= cu_count() * 7 / 4) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
     // fewer: the same tile, 8 waves on 128 rows.  Causal launches only: 256-byte rows have no non-causal instantiation of the two-wave tile
     // (GENERAL_ONLY in launch_dq_nw), and the general one measured +6 % there against the one-wave pipelined form
     if constexpr (bwd_ksplit<T, D, BIAS>()) {
@@ -1738,13 +1713,10 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if (p.dkv_splits > 1) return launch_dkv_nw<T, D, BIAS, 4>(p, s);       // split-query path: 128-key tiles x query ranges
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
     if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
-#ifndef FCSA_DKV_QSPLIT_BIAS
-#define FCSA_DKV_QSPLIT_BIAS 1
-#endif
-    if constexpr (bwd_ksplit<T, D, false>() && (D == 64 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16) && (!BIAS || FCSA_DKV_QSPLIT_BIAS != 0)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
+    if constexpr (bwd_ksplit<T, D, false>() && (D == 64 || D == 32 || D == 16)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
       const int KT4 = (p.M + 127) / 128;
       // (from 512 queries: below, the four or fewer 128-row tiles of a pass do not pay for the hand-over -- 23.5 vs 24.7 us at N = 333 / 777)
-      if (p.N >= 512 && (int64_t)p.B * p.H * (p.causal ? (KT4 + 1) / 2 : KT4) <= 256) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);
+      if (p.N >= 512 && (int64_t)p.B * p.H * (p.causal ? (KT4 + 1) / 2 : KT4) <= cu_count()) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);
     }
   } else if constexpr (Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES <= 256) {
     // lean form (two waves per SIMD, V fragments from the LDS) where an 8-wave workgroup per CU still covers the chip; smaller grids

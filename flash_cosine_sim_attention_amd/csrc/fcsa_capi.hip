@@ -112,10 +112,12 @@ constexpr float kStaticTop = 65.f, kStaticBottom = 85.f;      // exp(s - shift) 
 // shift; a strongly negative bias underflows to an exact 0 weight).  f16 does not: its static shift puts the largest logit at e^10 of a
 // 65504 range, so a bias of +1.1 on such a logit overflowed P~ to inf (found by an exploratory fuzz seed in round 3: f16, scale 1, bias
 // ~ N(0, 0.5)).  f16 problems WITH a bias therefore always take the per-row-reference form (whose online max includes the bias).
-// bf16 / f32 WITH a bias: the "+-20 around any shift" only holds while the window is not used up by the logits themselves; for
-// 60 < bound <= 75 a positive bias on a logit near the bound has e^23 ... e^8 of headroom before P~ or the row sum reach f32's top
-// (inf -> NaN rows), so those problems take the per-row form as well (round 3 review).
-constexpr float kStaticBoundBias = 60.f;
+// bf16 / f32 WITH a bias: the static window only has room for the bias while the logits themselves leave it: with shift = scale the
+// largest exponent is (bound - scale) + bias, and e^88 is f32's top (inf -> NaN rows).  Up to bound = scale * groups = 40 that leaves
+// a positive bias at least +45 of headroom on top of ln(M) for the row sum (the documented limit of the static form, include/fcsa.h);
+// beyond it -- round 3 drew the line at 60, where the headroom was down to +23 ... +36 (round 4 advice) -- problems with a bias take
+// the per-row form, whose online reference includes the bias and has no limit at all.
+constexpr float kStaticBoundBias = 40.f;
 bool dynamic_shift(const fcsa_problem& p, bool has_bias) {
   if (!p.l2norm_qk) return false;
   const float bound = fabsf(p.scale) * (float)p.groups;
@@ -150,11 +152,11 @@ struct BwdLayout {
 };
 
 // Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
-// workgroups for 256 CUs), the problem is not causal and every split keeps >= 512 keys.  Mirrors forward_splits: C4 (1 x 8 heads x
+// workgroups for 256 CUs; fcsa::cu_count()), the problem is not causal and every split keeps >= 512 keys.  Mirrors forward_splits: C4 (1 x 8 heads x
 // 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  The ONE definition both the workspace size and the launch use.
 // Target: the split kernels are the 4-wave (128-row) forms; where those run two waves per SIMD (rows <= 128 bytes) a CU wants TWO
-// workgroups, i.e. 512 on the chip, else 256.  (Round 2 aimed at 256 throughout: C4 ran its forward and dQ at half occupancy.)
-int split_target(const fcsa_problem& p) { return elem_size(p.dtype) * p.dim_head <= 128 ? 512 : 256; }
+// workgroups, i.e. 2 x CUs on the chip, else 1 x CUs.  (Round 2 aimed at 256 throughout: C4 ran its forward and dQ at half occupancy.)
+int split_target(const fcsa_problem& p) { return (elem_size(p.dtype) * p.dim_head <= 128 ? 2 : 1) * fcsa::cu_count(); }
 int backward_dq_splits(const fcsa_problem& p) {
   if (p.causal) return 1;
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
@@ -309,7 +311,7 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
 }
 
 // Split-key forward: how many workgroups share one row tile's key range.  Only where the 128-row tiles cannot fill the
-// chip (< 128 workgroups for 256 CUs), the problem is not causal (key ranges of a causal row tile are short and uneven),
+// chip (< 128 workgroups for 256 CUs; fcsa::cu_count()), the problem is not causal (key ranges of a causal row tile are short and uneven),
 // the static exponent shift applies (partials with a common shift add up exactly) and every split keeps >= 512 keys.
 static int forward_splits(const fcsa_problem& p) {
   if (p.causal || dynamic_shift(p, false)) return 1;      // (never called with a bias: fcsa_forward only splits bias-free problems)

@@ -157,18 +157,9 @@ template <typename T> FCSA_DEV f32x16 key_mask_rank1_cols(f32x16 c, bool key_mas
 // the barrier together (waits 7 - 9 % / 6 %; tile loops of dK/dV -10.7 %, of dQ -4.1 % in clocks).  The forward keeps age order
 // (kPrioFwd = 0): its interval is one 64-key tile with the barrier in its middle, and the balanced form measured +10 % clocks there --
 // the old half running ahead is what puts its MFMA phases beside the young half's exponentials.
-#ifndef FCSA_PRIO_BWD
-#define FCSA_PRIO_BWD 1
-#endif
-#ifndef FCSA_PRIO_FWD
-#define FCSA_PRIO_FWD 0
-#endif
-#ifndef FCSA_PRIO_LEAN
-#define FCSA_PRIO_LEAN 0
-#endif
-constexpr int kPrioLean = FCSA_PRIO_LEAN;      // the same idea in the lean (16-bit D = 96 / 128, two waves per SIMD) dK/dV form
-constexpr int kPrioBwd = FCSA_PRIO_BWD;
-constexpr int kPrioFwd = FCSA_PRIO_FWD;
+constexpr int kPrioLean = 0;      // the same idea in the lean (16-bit D = 96 / 128, two waves per SIMD) dK/dV form
+constexpr int kPrioBwd = 1;
+constexpr int kPrioFwd = 0;
 
 // A value the optimiser must treat as freshly computed here: keeps per-lane address arithmetic of prologues / epilogues from being
 // hoisted out of the pass loop, where it would stay live across the tile loops and push the kernels over their register budget

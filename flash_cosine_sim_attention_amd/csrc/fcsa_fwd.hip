@@ -18,7 +18,7 @@
 //     ds_read_b64_tr_b16 (no P~ round trip through shared memory, cf. cu:1222);
 //   * 16-bit types: the row sum is the exact f32 sum of the ROUNDED P~ that feeds P~V, so O is a true convex combination of
 //     V rows (the reference also sums the rounded tile, cu:1236): v_dot2c against packed ones, 8 per block and lane, one
-//     lane^32 add at the end (round 4; rounds 1 - 3 spent two all-ones MFMAs per block on it, see FCSA_FWD_ROWSUM_VALU);
+//     lane^32 add at the end (round 4; rounds 1 - 3 spent two all-ones MFMAs per block on it, kernel comment below);
 //     f32: per-lane adds plus one lane^32 add;
 //   * float32 inputs run the same skeleton on v_mfma_f32_32x32x2_f32 (exact f32, 1/16 of the bf16
 //     rate): P~ stays f32 and V^T comes from ds_read_b32 (fcsa_common.cuh), no transposed read;
@@ -46,20 +46,14 @@
 namespace fcsa {
 // 64-key tiles per LDS stage of fwd_kernel where the stages arrive by LDS-DMA.  One: this kernel's barrier sits in the MIDDLE of a
 // tile (mid()), where the old wave of a SIMD waits less than at a tile end; two per stage measured +1.8 % time at C3.
-#ifndef FCSA_FWD_SUB
-#define FCSA_FWD_SUB 1
-#endif
-constexpr int kFwdSub = FCSA_FWD_SUB;
+constexpr int kFwdSub = 1;
 // Row sums of the 16-bit forward forms.  Rounds 1 - 3 took them from the MATRIX pipe (an all-ones MFMA per 16-key step: exact f32 sums of
 // the rounded P~, 2 of a block's 10 MFMAs at D = 64); round 4 takes them from the VALU with v_dot2c_f32_{bf16,f16} against packed ones
 // (the same exact sums: 8 instructions per block and lane, one lane^32 add at the end).  Measured again because the kernels run at the
 // chip's power limit, where a fifth less MFMA work weighs more than eight VALU slots: C3 forward 83.3 -> 77.7 us (-6.7 %), lean D = 128
 // 136.9 -> 129.9, bias form 66.8 -> 63.2, online-reference form 93.8 -> 90.4 (profiles/r04_ab_rowsum_valu.txt).  (Round 2 measured
 // the same swap at +1 % -- before LDS-DMA staging, with the MFMA group hints still counting the two row-sum MFMAs.)
-// Bits: 1 = prefetching form (D <= 64), 2 = lean form (D = 96 / 128), 4 = generic block (bias, f32 keeps its per-lane adds).
-#ifndef FCSA_FWD_ROWSUM_VALU
-#define FCSA_FWD_ROWSUM_VALU 7
-#endif
+// All 16-bit forms (prefetching, lean, generic / bias) use the VALU sums; f32 keeps its per-lane adds.
 #ifdef FCSA_TRACE
 __device__ unsigned long long g_trace_fwd[128];
 #endif
@@ -184,14 +178,8 @@ FCSA_DEV void fwd_softmax_block(f32x16& s, SecondB<T>& pb, float& l, f32x16& lac
   }
   pb.prep(s);
   if constexpr (TR::ES == 2) {      // row sum of this block's 32 keys, of the ROUNDED P~
-#if FCSA_FWD_ROWSUM_VALU & 4
 #pragma unroll
     for (int e = 0; e < 8; ++e) l = TR::add_pair(pb.v[e >> 2][e & 3], l);
-#else
-    const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
-    lacc = TR::mfma32(ones, pb.v[0], lacc);
-    lacc = TR::mfma32(ones, pb.v[1], lacc);
-#endif
   }
 }
 
@@ -230,9 +218,6 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
   if constexpr (LEAN) {
     // per 32-key block: K fragments (4 k-steps at a time) -> S chain; V fragments of the block requested behind the chain, landing
     // during exp / pack; row sum on the matrix pipe; PV.  Everything is read from the LDS tile here (`kf` is unused).
-#if !(FCSA_FWD_ROWSUM_VALU & 2)
-    const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
-#endif
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
       f32x16 s;
@@ -276,13 +261,8 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       }
       SecondB<T> pb;
       pb.prep(s);
-#if FCSA_FWD_ROWSUM_VALU & 2
 #pragma unroll
       for (int e = 0; e < 8; ++e) l = TR::add_pair(pb.v[e >> 2][e & 3], l);
-#else
-      lacc = TR::mfma32(ones, pb.v[0], lacc);
-      lacc = TR::mfma32(ones, pb.v[1], lacc);
-#endif
 #pragma unroll
       for (int db = 0; db < G::DB; ++db) {
         o[db] = TR::mfma32(vf[db][0], pb.v[0], o[db]);
@@ -380,16 +360,8 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
         for (int kk = 0; kk < G::KS; ++kk) kf[jb][kk] = fa.row_frag(knext, 32 * jb, kk);
     }
     // --- PV of block 0 (row sum + DB output blocks) interleaved with exp / pack of block 1
-#if !(FCSA_FWD_ROWSUM_VALU & 1)
-    const u32x4 ones = {TR::kOne2, TR::kOne2, TR::kOne2, TR::kOne2};
-#endif
-#if FCSA_FWD_ROWSUM_VALU & 1
 #pragma unroll
     for (int e = 0; e < 8; ++e) l = TR::add_pair(pb0.v[e >> 2][e & 3], l);
-#else
-    lacc = TR::mfma32(ones, pb0.v[0], lacc);
-    lacc = TR::mfma32(ones, pb0.v[1], lacc);
-#endif
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
       o[db] = TR::mfma32(vf0[db][0], pb0.v[0], o[db]);
@@ -402,7 +374,7 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
       s1[r] = e;
     }
     pb1.prep(s1);
-    constexpr int NPV = ((FCSA_FWD_ROWSUM_VALU & 1) ? 0 : 2) + 2 * G::DB;
+    constexpr int NPV = 2 * G::DB;
 #pragma unroll
     for (int m = 0; m < NPV; ++m) {
       __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
@@ -412,13 +384,8 @@ FCSA_DEV void fwd_tile(const char* vt, u32x4 (&kf)[2][TileGeom<D, Traits<T>::ES>
     __builtin_amdgcn_sched_barrier(0);
     FCSA_STAMP(ts, 8);
     // --- PV of block 1
-#if FCSA_FWD_ROWSUM_VALU & 1
 #pragma unroll
     for (int e = 0; e < 8; ++e) l = TR::add_pair(pb1.v[e >> 2][e & 3], l);
-#else
-    lacc = TR::mfma32(ones, pb1.v[0], lacc);
-    lacc = TR::mfma32(ones, pb1.v[1], lacc);
-#endif
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) {
       o[db] = TR::mfma32(vf1[db][0], pb1.v[0], o[db]);
@@ -678,7 +645,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l = 0.f;          // f32: per-lane partial row sum
-  f32x16 lacc;            // 16 bit: row sums from the ones-MFMA (every register holds the full sum of column i)
+  f32x16 lacc;            // (rounds 1 - 3: row sums from an all-ones MFMA; stays zero since the 16-bit sums moved to the VALU, kept for the online-reference plumbing)
 #pragma unroll
   for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
 
@@ -912,11 +879,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   // pass may overwrite buffer 0 in its prologue
 
   // epilogue: normalise and store.  Lane (i, hi) holds O[i][32*db + 8*rq + 4*hi + 0..3].
-#if FCSA_FWD_ROWSUM_VALU
   float lt = (TR::ES == 2) ? lacc[0] + xhalf_sum(l) : xhalf_sum(l);
-#else
-  float lt = (TR::ES == 2) ? lacc[0] : xhalf_sum(l);
-#endif
   if constexpr (KSPLIT) {
     // the odd-tile half hands its partials to the even-tile half of the same rows through the LDS (the staging buffers are free:
     // every wave's last LDS read came before the last stage barrier); 16-byte accesses, lane-contiguous
@@ -1358,26 +1321,14 @@ static hipError_t launch_fwd2(const FwdParams& p, hipStream_t s) {
 // staged once per CU instead of twice, i.e. half the global loads and LDS stores per wave (C3: forward -6%).
 static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
   const int MT = (rows + 255) / 256;
-  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= 224 ? 8 : 4;
+  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8 ? 8 : 4;
 }
 
 // Key-split form (fwd_kernel<.., KSPLIT>): 128-row workgroups of 8 waves.  Where the 128-row four-wave workgroups would leave the SIMDs
 // with one wave each: rows wider than 128 bytes always (that form runs one wave per SIMD whatever the grid), narrower rows when the grid
 // has fewer than ~1.5 workgroups per CU.
-#ifndef FCSA_FWD_KSPLIT
-#define FCSA_FWD_KSPLIT 1
-#endif
-#ifndef FCSA_KSPLIT_D32
-#define FCSA_KSPLIT_D32 32      // (0: not at D = 32)
-#endif
-#ifndef FCSA_KSPLIT_D16
-#define FCSA_KSPLIT_D16 16      // (0: not at D = 16)
-#endif
-#ifndef FCSA_FWD_KSPLIT_BIAS
-#define FCSA_FWD_KSPLIT_BIAS 1
-#endif
 template <typename T, int D, bool BIAS> constexpr bool fwd_ksplit() {
-  return FCSA_FWD_KSPLIT != 0 && Traits<T>::ES == 2 && (BIAS ? (FCSA_FWD_KSPLIT_BIAS != 0 && (D == 64 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16)) : (D == 64 || D == 96 || D == 128 || D == FCSA_KSPLIT_D32 || D == FCSA_KSPLIT_D16)) &&
+  return Traits<T>::ES == 2 && (BIAS ? (D == 64 || D == 32 || D == 16) : (D == 64 || D == 96 || D == 128 || D == 32 || D == 16)) &&
          (64 * TileGeom<D, Traits<T>::ES>::ROWB) % 1024 == 0;
 }
 template <typename T, int D>
@@ -1385,10 +1336,7 @@ static bool use_ksplit_fwd(const FwdParams& p) {
   const int MT = (p.N + 127) / 128;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT) * (p.splits > 1 ? p.splits : 1);
   if (D * Traits<T>::ES > 128) return true;
-#ifndef FCSA_KSPLIT_WGS
-#define FCSA_KSPLIT_WGS 256
-#endif
-  return wgs <= FCSA_KSPLIT_WGS;
+  return wgs <= cu_count();
 }
 
 // Split-key forward, second step: O = (sum_s partial P~V) / max(sum_s partial l, eps), inv_l alike.  One thread per

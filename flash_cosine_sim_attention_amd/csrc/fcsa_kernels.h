@@ -97,6 +97,23 @@ static inline hipError_t ensure_dynamic_lds(K kern, size_t lds, std::atomic<uint
   return e;
 }
 
+// Compute units of the device the launch heuristics are sized for: queried ONCE per process (the current device at the first call; a
+// node's devices are alike), 256 when no device answers (host-only callers: workspace-size queries in the CPU tests).  Every "does
+// this grid cover the chip" threshold of the launchers and of the C ABI's split rules is a multiple of this number, so the workspace
+// size a caller is told and the launch that uses it always agree.
+inline int cu_count() {
+  static std::atomic<int> cached{0};
+  int n = cached.load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();      // a host without a device: do not leave a sticky error behind
+    cus = 256;
+  }
+  cached.store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
 // dtype: 1 = f16, 2 = bf16 (fcsa_dtype); returns hipError_t of the launch
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s);

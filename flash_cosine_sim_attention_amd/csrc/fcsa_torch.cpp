@@ -363,12 +363,12 @@ extern "C" int fcsa_torch_use_library(const char* path) {
   a.backward_ws = reinterpret_cast<decltype(a.backward_ws)>(dlsym(h, "fcsa_backward_workspace_bytes"));
   a.needs_qn = reinterpret_cast<decltype(a.needs_qn)>(dlsym(h, "fcsa_forward_needs_qn"));
   a.last_error = reinterpret_cast<decltype(a.last_error)>(dlsym(h, "fcsa_last_error"));
-  if (!a.forward || !a.backward || !a.forward_ws || !a.backward_ws || !a.needs_qn || !a.last_error) return -2;
+  if (!a.forward || !a.backward || !a.forward_ws || !a.backward_ws || !a.needs_qn || !a.last_error) { dlclose(h); return -2; }
   // Only libraries of THIS ABI: the binding allocates for the struct layouts and buffer contracts of include/fcsa.h as compiled in
   // (e.g. ABI 3 writes d_bias once in the bias dtype into an uninitialised buffer; an ABI-2 library would accumulate float32 into
   // it -- twice the buffer's size for the 16-bit types).  -3: the library reports another version.
   auto dbg = reinterpret_cast<int (*)(char*, size_t)>(dlsym(h, "fcsa_debug"));
-  if (!dbg || dbg(nullptr, 0) != FCSA_ABI_VERSION) return -3;
+  if (!dbg || dbg(nullptr, 0) != FCSA_ABI_VERSION) { dlclose(h); return -3; }
   g_abi = a;
   return 0;
 }

@@ -86,13 +86,20 @@ typedef struct fcsa_problem {
   float   scale;            /* logits = scale * qh.kh ; reference exponent shift = -scale (cu:1216).
                                With l2norm_qk the logit range is +-|scale|*groups.  Where no constant shift fits that
                                range into the exponent of the type P is rounded to (float16: |scale|*groups > 11, or any
-                               attn_bias -- a bias is unbounded and float16 has no room for it; else > 75) the forward
+                               attn_bias -- a bias is unbounded and float16 has no room for it; bfloat16 / float32: > 75,
+                               or > 40 with an attn_bias) the forward
                                kernel keeps a per-row exponent reference (online max), normalises the row exactly (no
                                1e-10 clamp: in exp(S - scale) units that clamp would attenuate or zero rows there; the
                                reference kernel itself overflows / zeroes) and saves log2 of the normaliser instead of
                                the normaliser, so any finite scale the public signature admits runs
                                (flash_cosine_sim_attention.py:308-319 has no limit).  Only float16 with
-                               |scale| * log2(e) > 60000 is refused: the folded c1 * q^ would leave the type. */
+                               |scale| * log2(e) > 60000 is refused: the folded c1 * q^ would leave the type.
+                               Supported attn_bias magnitude: float16 and every per-row-reference problem: any finite bias
+                               (the online reference includes it).  bfloat16 / float32 with |scale|*groups <= 40 use the
+                               constant shift: bias values up to +45 above the largest logit are exact (exp stays below
+                               float32's e^88 with ln(M) to spare for the row sum); larger positive values can overflow a
+                               row to inf/NaN -- the reference's float32 exp(S - scale + bias) has the same limit at +88 --
+                               and strongly negative values underflow to an exact 0 weight, as in the reference. */
 } fcsa_problem;
 
 /* State the fused-l2norm forward saves for backward (all caller-allocated, contiguous):

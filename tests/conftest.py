@@ -27,3 +27,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_report_header(config):
+    """First lines of every pytest log: how many GPUs this process sees (the two-device test of test_gpu_misc.py only runs with >= 2)
+    and which native libraries the package will load -- evidence that travels with the log copied to profiles/."""
+    try:
+        import torch
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        names = [torch.cuda.get_device_name(i) for i in range(n)]
+    except Exception as ex:  # pragma: no cover
+        n, names = 0, [repr(ex)]
+    pkg = os.path.join(ROOT, "flash_cosine_sim_attention_amd")
+    libs = [f for f in sorted(os.listdir(pkg)) if f.endswith(".so")]
+    return ["fcsa: torch.cuda.device_count() = %d %s; HIP_VISIBLE_DEVICES=%r" % (n, names, os.environ.get("HIP_VISIBLE_DEVICES")),
+            "fcsa: native libraries in the package: %s" % libs]

@@ -97,7 +97,7 @@ def dynamic_shift_regime(dtype, scale, groups, l2norm, bias):
         return False
     if dtype == "f16":
         return bound > 11 or bool(bias)
-    return bound > 75 or (bool(bias) and bound > 60)
+    return bound > 75 or (bool(bias) and bound > 40)
 
 
 def op_kwargs(case):

@@ -184,7 +184,9 @@ def test_backward_fullsize_identities_and_slices(name):
     single = k.dim() == 3
     rel = lambda a, r: ((a.float() - r).norm() / r.norm()).item()
     cond = max(1.0, cfg["scale"] * cfg["groups"] / 16.0)
-    tol = (1.2e-2 if bf else 3e-3) * cond
+    import tolerances as T
+    dtn = "bf16" if bf else "f16"
+    tol = T.GRAD_TOL[dtn] * cond
     dk_ref = dv_ref = None
     for h in (range(cfg["q"][1]) if single else (1,)):
         qs = q.detach()[b, h].float().requires_grad_()
@@ -193,26 +195,26 @@ def test_backward_fullsize_identities_and_slices(name):
         ref = _ref_slice(qs, ks, vs, None if mask is None else mask[b], cfg["causal"], cfg["scale"], cfg["groups"])
         (ref * do[b, h].float()).sum().backward()
         if h in (1, cfg["q"][1] - 1):
-            assert rel(dq[b, h], qs.grad) <= tol, (h, rel(dq[b, h], qs.grad))
+            assert T.check("fullsize/grad raw", dtn, rel(dq[b, h], qs.grad), tol, name), (h, rel(dq[b, h], qs.grad))
         dk_ref = ks.grad if dk_ref is None else dk_ref + ks.grad
         dv_ref = vs.grad if dv_ref is None else dv_ref + vs.grad
     dk_got, dv_got = (dk[b], dv[b]) if single else (dk[b, 1], dv[b, 1])
-    assert rel(dk_got, dk_ref) <= tol, rel(dk_got, dk_ref)
-    assert rel(dv_got, dv_ref) <= tol, rel(dv_got, dv_ref)
+    assert T.check("fullsize/grad raw", dtn, rel(dk_got, dk_ref), tol, name), rel(dk_got, dk_ref)
+    assert T.check("fullsize/grad raw", dtn, rel(dv_got, dv_ref), tol, name), rel(dv_got, dv_ref)
     # the same slices against exact float64 math on the 16-bit OPERANDS: the FIXED bars, at every scale * groups (the twin of the
     # range-scaled comparison above; round 3 had it for the forward only)
-    tol1 = 1.2e-2 if bf else 3e-3
+    tol1 = T.GRAD_TOL[dtn]
     dk_ref = dv_ref = None
     for h in (range(cfg["q"][1]) if single else (1,)):
         kk, vv = (k.detach()[b], v.detach()[b]) if single else (k.detach()[b, h], v.detach()[b, h])
         rdq, rdk, rdv = _grads_operand_faithful(q.detach()[b, h], kk, vv, do[b, h], None if mask is None else mask[b], cfg["causal"],
                                                 cfg["scale"], cfg["groups"], cfg["dtype"])
         if h in (1, cfg["q"][1] - 1):
-            assert rel(dq[b, h], rdq) <= tol1, ("dq vs 16-bit operands", h, rel(dq[b, h], rdq))
+            assert T.check("fullsize/grad 16-bit operands", dtn, rel(dq[b, h], rdq), tol1, name), ("dq vs 16-bit operands", h, rel(dq[b, h], rdq))
         dk_ref = rdk if dk_ref is None else dk_ref + rdk
         dv_ref = rdv if dv_ref is None else dv_ref + rdv
-    assert rel(dk_got, dk_ref) <= tol1, ("dk vs 16-bit operands", rel(dk_got, dk_ref))
-    assert rel(dv_got, dv_ref) <= tol1, ("dv vs 16-bit operands", rel(dv_got, dv_ref))
+    assert T.check("fullsize/grad 16-bit operands", dtn, rel(dk_got, dk_ref), tol1, name), ("dk vs 16-bit operands", rel(dk_got, dk_ref))
+    assert T.check("fullsize/grad 16-bit operands", dtn, rel(dv_got, dv_ref), tol1, name), ("dv vs 16-bit operands", rel(dv_got, dv_ref))
 
 
 def test_operand_faithful_helper_equals_the_numpy_oracle():

@@ -28,8 +28,9 @@ from oracle import cosine_sim_oracle as O
 pytestmark = pytest.mark.gpu
 
 DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
-FWD_TOL = {"f16": (5e-3, 2.0 ** -10), "bf16": (2e-2, 2.0 ** -7), "f32": (2e-5, 2e-5)}
-GRAD_TOL = {"f16": 3e-3, "bf16": 1.2e-2, "f32": 2e-5}
+import tolerances as T
+FWD_TOL = {d: t[:2] for d, t in T.FWD_TOL.items()}      # (atol, rtol) -- tests/tolerances.py
+GRAD_TOL = T.GRAD_TOL
 
 
 def _configs(n_cases=96, seed=20260926):
@@ -204,10 +205,17 @@ def evaluate(cfg, raw=True):
             yield f"{pr}: {name} rel-L2", rel, lim
 
 
+def _cls(what):      # class of a comparison for the tolerance log: drop the (b, h) prefix and the gradient's name
+    w = what.split(": ", 1)[-1]
+    for n in ("dq ", "dk ", "dv "):
+        w = w.replace(n, "grad ")
+    return w
+
+
 @pytest.mark.parametrize("cfg", _configs() + _configs_long() + _configs_mid(), ids=lambda c: c["id"])
 def test_random_config_matches_oracle(cfg):
     for what, got, lim in evaluate(cfg):
-        assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"
+        assert T.check("fuzz/" + _cls(what), cfg["dtype"], got, lim, cfg["id"]), f"{cfg} {what} {got:.3e} > {lim}"
 
 
 def _named(id, **kw):
@@ -287,4 +295,20 @@ def test_named_case_operand_faithful(cfg):
     for what, got, lim in evaluate(cfg, raw=False):
         if two and "rel-L2" in what:
             lim *= 2.0
-        assert got <= lim, f"{cfg} {what} {got:.3e} > {lim}"
+        assert T.check("named/" + _cls(what), cfg["dtype"], got, lim, cfg["id"]), f"{cfg} {what} {got:.3e} > {lim}"
+
+
+# The same named cases against exact float64 math ON THE RAW INPUTS (nothing the kernels produced feeds the oracle: delta comes from the
+# oracle's own forward), with the range-scaled bars of test_random_config_matches_oracle -- the split forms K1 - K29 get their gradient
+# check independent of the tested forward here (round 4 review).  Not in this list: X1 - X4, X11, X12 -- the documented exceedance class
+# above (scale * groups = 64 on a handful of rows / two-feature l2norm groups / one concentrated row), whose raw-input error is the 16-bit
+# rounding of q^, k^ amplified beyond what the range factor models; they keep the operand-faithful comparison only.
+RAW_CASES = [c for c in NAMED_CASES if c["id"].split("_")[0] not in ("X1", "X2", "X3", "X4", "X11", "X12")]
+
+
+@pytest.mark.parametrize("cfg", RAW_CASES, ids=lambda c: c["id"])
+def test_named_case_raw_inputs(cfg):
+    for what, got, lim in evaluate(cfg, raw=True):
+        if "16-bit operands" in what:
+            continue                      # (test_named_case_operand_faithful)
+        assert T.check("named-raw/" + _cls(what), cfg["dtype"], got, lim, cfg["id"]), f"{cfg} {what} {got:.3e} > {lim}"

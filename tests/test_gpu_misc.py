@@ -291,8 +291,9 @@ def test_python_autograd_function_golden(name):
     inp = C.make_inputs(case, device="cuda")
     kw = C.op_kwargs(case)
     args = lambda q, k, v, b: (q, k, v, inp["mask"], b, kw["scale"], kw["groups"], kw["causal"], kw["l2norm_qk"], kw["attn_bias_batch_dim"])
-    gtol = {"f32": 2e-5, "f16": 3e-3, "bf16": 1.2e-2}[case["dtype"]]
-    atol = {"f32": 2e-5, "f16": 5e-3, "bf16": 2e-2}[case["dtype"]]
+    import tolerances as T
+    gtol = T.GRAD_TOL[case["dtype"]]
+    atol = T.FWD_TOL[case["dtype"]][0]
     rel = lambda a, r: float(np.linalg.norm(a.detach().double().cpu().numpy() - r) / max(np.linalg.norm(r), 1e-3 * np.sqrt(r.size)))
     # all inputs require grad
     q, k, v = (inp[n].clone().requires_grad_() for n in ("q", "k", "v"))
@@ -301,7 +302,8 @@ def test_python_autograd_function_golden(name):
     assert o.grad_fn is not None and type(o.grad_fn).__name__.startswith("FlashCosineSimAttention")
     o.backward(inp["do"])
     assert np.abs(o.detach().double().cpu().numpy() - gold["o_plain"]).max() <= atol + 2.0 ** -7 * np.abs(gold["o_plain"]).max()
-    assert rel(q.grad, gold["dq"]) <= gtol and rel(k.grad, gold["dk"]) <= gtol and rel(v.grad, gold["dv"]) <= gtol
+    for g_, nm in ((q.grad, "dq"), (k.grad, "dk"), (v.grad, "dv")):
+        assert T.check("fixture/grad", case["dtype"], rel(g_, gold[nm]), gtol, name), nm
     if bias is not None:
         assert bias.grad.dtype == bias.dtype and rel(bias.grad, gold["db"]) <= 1.5 * gtol
     # the same numbers as the C++ node gives (one implementation underneath: bit-identical)

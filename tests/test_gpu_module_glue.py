@@ -113,3 +113,37 @@ def test_smoke_train_learns_and_tracks_composite():
     assert f[0] > 5.0 and all(math.isfinite(x) for x in f)
     assert sum(f[-5:]) / 5 < 0.6 * f[0], f"did not learn: {f[0]:.3f} -> {sum(f[-5:]) / 5:.3f}"
     assert abs(sum(f[-5:]) - sum(p[-5:])) / sum(p[-5:]) < 0.15, (f[-5:], p[-5:])
+
+
+def test_amp_gradscaler_train_step_like_reference():
+    """The reference's train step (train.py:98-117): float16 autocast + GradScaler, gradient accumulation, unscale_, clip, scaler.step,
+    scaler.update.  The scaled loss multiplies dO by 2^16: the fused backward must hand back finite, correctly scaled gradients (the
+    scaler finds no inf and does not skip the step), the parameters move, and the unscaled gradients agree with the composite's."""
+    import flash_cosine_sim_attention_amd as F
+    grads, steps = {}, {}
+    for key, fn in (("fused", F.flash_cosine_sim_attention), ("plain", F.plain_cosine_sim_attention)):
+        torch.manual_seed(0)
+        model = TinyCausalLM(fn, groups=2).cuda()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=2.0 ** 14)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        before = [p.detach().clone() for p in model.parameters()]
+        for it in range(3):
+            opt.zero_grad()
+            for _ in range(2):                                        # GRADIENT_ACCUMULATE_EVERY
+                loss = _loss(model, _batch(gen, 4, 200), torch.float16)
+                scaler.scale(loss / 2).backward()
+            scaler.unscale_(opt)
+            if it == 0:
+                grads[key] = [p.grad.detach().clone() for p in model.parameters()]
+            assert all(torch.isfinite(p.grad).all() for p in model.parameters()), f"{key}: non-finite unscaled gradient"
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+            scale_before = scaler.get_scale()
+            scaler.step(opt)
+            scaler.update()
+            assert scaler.get_scale() >= scale_before, f"{key}: the scaler found an inf and backed off at step {it}"
+        steps[key] = sum((p.detach() - b).abs().sum().item() for p, b in zip(model.parameters(), before))
+        assert steps[key] > 0, f"{key}: optimizer steps were skipped"
+    for a, b in zip(grads["fused"], grads["plain"]):
+        rel = (a - b).norm() / b.norm().clamp_min(1e-6)
+        assert rel.item() <= 2e-2, f"unscaled grad rel-L2 {rel.item():.3e}"

@@ -25,18 +25,18 @@ import pytest
 import torch
 
 import cases as C
+import tolerances as T
 from oracle import cosine_sim_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
-FWD_TOL = {"f16": (5e-3, 2.0 ** -10, 1e-3), "bf16": (2e-2, 2.0 ** -7, 5e-3), "f32": (2e-5, 2e-5, 1e-5)}   # atol, rtol, rel-L2
-GRAD_TOL = {"f16": 3e-3, "bf16": 1.2e-2, "f32": 2e-5}
+FWD_TOL, GRAD_TOL = T.FWD_TOL, T.GRAD_TOL      # (atol, rtol, rel-L2) forward; rel-L2 gradients -- tests/tolerances.py
 
 
-def _close(got, ref, dtype, cond=1.0):
+def _close(got, ref, dtype, cond=1.0, label="parity/fwd-excess"):
     atol, rtol, _ = FWD_TOL[dtype]
-    return float((np.abs(got - ref) - rtol * np.abs(ref)).max()) <= atol * cond
+    return T.check(label, dtype, float((np.abs(got - ref) - rtol * np.abs(ref)).max()), atol * cond)
 
 
 def _supported(dtype):
@@ -96,7 +96,7 @@ def _run_case(case, check_grads=True):
         what = "raw inputs" if operand_dtype is None else "16-bit operands"
         ref_o, _ = O.attention_forward_stats(npi["q"], npi["k"], npi["v"], operand_dtype=operand_dtype, **okw)
         assert _close(got, ref_o, dtype, c), f"fwd vs {what}: max-abs {np.abs(got - ref_o).max():.3e}"
-        assert _rel(got, ref_o) <= FWD_TOL[dtype][2] * c, f"fwd vs {what}: rel-L2 {_rel(got, ref_o):.3e}"
+        assert T.check("parity/fwd-rel/" + what, dtype, _rel(got, ref_o), FWD_TOL[dtype][2] * c, case.get("name")), f"fwd vs {what}: rel-L2 {_rel(got, ref_o):.3e}"
         if not check_grads:
             continue
         rdq, rdk, rdv, rdb = O.attention_backward(npi["do"], npi["q"], npi["k"], npi["v"], operand_dtype=operand_dtype, **okw)
@@ -105,11 +105,11 @@ def _run_case(case, check_grads=True):
             g = _np(got_t)
             assert g.shape == ref.shape, name
             assert np.isfinite(g).all(), name
-            assert _rel(g, ref) <= gt, f"{name} vs {what}: rel-L2 {_rel(g, ref):.3e}"
+            assert T.check("parity/grad/" + what, dtype, _rel(g, ref), gt, case.get("name")), f"{name} vs {what}: rel-L2 {_rel(g, ref):.3e}"
         if bias is not None:
             g = _np(bias.grad)
             assert np.isfinite(g).all()
-            assert _rel(g, rdb) <= gt * 1.5, f"db vs {what}: rel-L2 {_rel(g, rdb):.3e}"
+            assert T.check("parity/dbias/" + what, dtype, _rel(g, rdb), gt * 1.5, case.get("name")), f"db vs {what}: rel-L2 {_rel(g, rdb):.3e}"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -135,14 +135,13 @@ def test_golden_case_vs_reference_fixture(case):
     ok = _valid_rows(case["n"], case["m"], case["b"], case["causal"], _np(inp["mask"]), case["merged"])
     okb = np.broadcast_to(ok[..., None], gold["o_plain"].shape)
     cond = C.logit_cond(case["dtype"], case["scale"], case["groups"], case["l2norm"])      # (1 for every case but the `wide` ones)
-    assert _close(np.where(okb, _np(o), 0.0), np.where(okb, gold["o_plain"], 0.0), case["dtype"], cond)
+    assert _close(np.where(okb, _np(o), 0.0), np.where(okb, gold["o_plain"], 0.0), case["dtype"], cond, "fixture/fwd-excess")
     if ok.all():
         gt = GRAD_TOL[case["dtype"]] * cond
-        assert _rel(_np(q.grad), gold["dq"]) <= gt
-        assert _rel(_np(k.grad), gold["dk"]) <= gt
-        assert _rel(_np(v.grad), gold["dv"]) <= gt
+        for nm, g_ in (("dq", q.grad), ("dk", k.grad), ("dv", v.grad)):
+            assert T.check("fixture/grad", case["dtype"], _rel(_np(g_), gold[nm]), gt, case["name"]), nm
         if bias is not None:
-            assert _rel(_np(bias.grad), gold["db"]) <= gt * 1.5
+            assert T.check("fixture/dbias", case["dtype"], _rel(_np(bias.grad), gold["db"]), gt * 1.5, case["name"])
 
 
 # ------------------------------------------------------------------------------------------------

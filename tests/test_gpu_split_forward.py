@@ -12,8 +12,9 @@ from oracle import cosine_sim_oracle as O
 pytestmark = pytest.mark.gpu
 
 DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
-FWD_TOL = {"f16": (5e-3, 2.0 ** -10), "bf16": (2e-2, 2.0 ** -7), "f32": (2e-5, 2e-5)}
-GRAD_TOL = {"f16": 3e-3, "bf16": 1.2e-2, "f32": 2e-5}
+import tolerances as T
+FWD_TOL = {d: t[:2] for d, t in T.FWD_TOL.items()}      # (atol, rtol) -- tests/tolerances.py
+GRAD_TOL = T.GRAD_TOL
 
 CASES = [
     # dtype, B, H, N,   M,    D,  mask,  single_kv, l2norm, groups
@@ -61,11 +62,11 @@ def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv,
     ro, _ = O.attention_forward_stats(_npf(q), _npf(k), _npf(v), **kw)
     atol, rtol = FWD_TOL[dtype]
     excess = (np.abs(_npf(o) - ro) - rtol * np.abs(ro)).max()
-    assert excess <= atol * max(np.abs(_npf(v)).max(), 1.0), f"forward excess {excess:.3e}"
+    assert T.check("split/forward excess", dtype, excess, atol * max(np.abs(_npf(v)).max(), 1.0)), f"forward excess {excess:.3e}"
     rdq, rdk, rdv, _ = O.attention_backward(_npf(do), _npf(q), _npf(k), _npf(v), **kw)
     for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
         rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
-        assert rel <= GRAD_TOL[dtype], f"{name} rel-L2 {rel:.3e}"
+        assert T.check("split/grad rel-L2", dtype, rel, GRAD_TOL[dtype]), f"{name} rel-L2 {rel:.3e}"
 
 
 def test_split_and_unsplit_agree_through_the_c_abi():
@@ -146,4 +147,4 @@ def test_split_query_dkv_matches_oracle(dtype, B, H, N, M, D, use_mask, l2norm, 
     for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
         assert torch.isfinite(got).all(), name
         rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
-        assert rel <= GRAD_TOL[dtype], f"{name} rel-L2 {rel:.3e}"
+        assert T.check("split/grad rel-L2", dtype, rel, GRAD_TOL[dtype]), f"{name} rel-L2 {rel:.3e}"
