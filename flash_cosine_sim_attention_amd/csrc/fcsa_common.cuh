@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fcsa_kernels.h"
 
 namespace fcsa {
 
@@ -818,6 +819,78 @@ FCSA_DEV void block_to_work(int id, int n_bh, int n_tiles, int& bh, int& tile) {
     bh = id / n_tiles;
     tile = id % n_tiles;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Query rows of the forward kernels (fcsa_fwd.hip, fcsa_fwd3.hip)
+// ---------------------------------------------------------------------------------------------
+// Q fragments of query row i (B operand of S^T = K Q^T): lane (i, hi) holds the 16-byte chunks 2*kk + hi, so the lane
+// pair of a row holds the whole row.  Three input forms:
+//   q_raw    : RAW q (fused l2norm, 16-bit types, group size 8 * 2^lgm).  The grouped l2norm (reference py:50-55,
+//              F.normalize eps 1e-12) is done here in registers: per-chunk sums of squares, one lane^32 add per k-step,
+//              r = 1 / max(||q_g||, eps), q^ * c1 rounded ONCE to the 16-bit type -- bit-identical to what l2norm_kernel
+//              writes -- and published (qn_out, rq_out) for the backward kernels.  Saves the separate HBM pass over q.
+//   q_scaled : c1 * q^ already (written by l2norm_kernel: f32, odd group sizes)
+//   else     : q^ as given (the reference extension's contract); c1 is folded in here
+template <typename T, int D>
+FCSA_DEV void request_q_rows(const FwdParams& p, int b, int h, int i, int hi, u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS]) {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  const char* qrow = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh + (int64_t)i * p.q.sn;
+#pragma unroll
+  for (int kk = 0; kk < G::KS; ++kk) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    qf[kk] = z;
+    if (i < p.N) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + (2 * kk + hi) * 16);
+  }
+}
+// raw row chunks (request_q_rows) -> B operands of the S chains: fused (grouped) l2norm with the c1 * q^ / inverse-norm outputs
+// the backward reads, or the plain c1 scaling
+template <typename T, int D, bool OPQ = false>
+FCSA_DEV void finish_q_frags(const FwdParams& p, int b, int h, int i, const FragAddr<T, D>& fa,
+                             u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS], bool publish = true) {
+  typedef TileGeom<D, Traits<T>::ES> G;
+  if constexpr (Traits<T>::ES == 2) {
+    if (p.q_raw) {
+      float pair[G::KS];
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) {
+        const float ss = dot_frag<T>(qf[kk], qf[kk]);
+        pair[kk] = p.lgm >= 1 ? xhalf_sum(ss) : ss;      // groups of >= 16 features contain both chunks of a k-step
+      }
+      const int sh = p.lgm >= 1 ? p.lgm - 1 : 0;         // k-steps per group = 1 << sh
+      const int64_t row = ((int64_t)b * p.H + h) * p.N + i;
+      // (the lane half comes from an opaque value: derived from fa.hi, the 2 * KS lane-constant address pairs of the conditional
+      //  stores below are hoisted to kernel entry, live across the whole kernel and get spilled in the wider instantiations)
+      //  (OPQ: the lean two-waves-per-SIMD forms and the bias + dynamic-shift kernel.  The others keep the hoisted form: with it the C3
+      //   kernel measured 1.3 % faster, registers are not its limit)
+      const int hi_ = OPQ ? opaque(fa.hi) : fa.hi;
+#pragma unroll
+      for (int kk = 0; kk < G::KS; ++kk) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < G::KS; ++k2) tot += ((k2 >> sh) == (kk >> sh)) ? pair[k2] : 0.f;
+        const float r = 1.f / fmaxf(sqrtf(tot), p.norm_eps);
+        qf[kk] = scale_frag<T>(qf[kk], r * p.c1);
+        if (i < p.N && publish) {
+          const int c = 2 * kk + hi_;
+          if (p.qn_out != nullptr) *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];      // (inference: nothing is saved)
+          if (p.rq_out != nullptr && (c & ((1 << p.lgm) - 1)) == 0) p.rq_out[row * p.G + (c >> p.lgm)] = r;
+        }
+      }
+      return;
+    }
+  }
+  if (!p.q_scaled) {
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) qf[kk] = scale_frag<T>(qf[kk], p.c1);
+  }
+}
+
+template <typename T, int D>
+FCSA_DEV void load_q_frags(const FwdParams& p, int b, int h, int i, const FragAddr<T, D>& fa,
+                           u32x4 (&qf)[TileGeom<D, Traits<T>::ES>::KS]) {
+  request_q_rows<T, D>(p, b, h, i, fa.hi, qf);
+  finish_q_frags<T, D>(p, b, h, i, fa, qf);
 }
 
 }  // namespace fcsa

@@ -116,6 +116,9 @@ inline int cu_count() {
 
 // dtype: 1 = f16, 2 = bf16 (fcsa_dtype); returns hipError_t of the launch
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
+// fcsa_fwd3.hip: the 64-rows-per-wave, one-wave-per-SIMD forward for 16-bit D = 128 (launch_forward dispatches to it)
+bool use_forward_wide128(int dtype, int D, const FwdParams& p);
+hipError_t launch_forward_wide128(int dtype, const FwdParams& p, hipStream_t s);
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s);
 hipError_t launch_backward_dbias(int dtype, int D, const BwdParams& p, hipStream_t s);   // d_bias from recomputed dS tiles (after dq: needs delta)
 hipError_t launch_backward_dkv(int dtype, int D, const BwdParams& p, hipStream_t s);
