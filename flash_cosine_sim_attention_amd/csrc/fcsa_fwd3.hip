@@ -90,13 +90,18 @@ template <typename T> struct F3State {
 };
 
 // softmax item E (0..7) of one [32 keys x 32 rows] block = accumulator registers 2E, 2E + 1: (select,) exp | add, pack
-template <bool MASKED, int E, int KOFF> FCSA_DEV void sm_exp(f32x16& s, int thr, float ninf) {
+template <bool MASKED, int E, int KOFF, int ABL = 0> FCSA_DEV void sm_exp(f32x16& s, int thr, float ninf) {
   if constexpr (MASKED) {      // key row KOFF + crow(r, 0) (relative to this lane's threshold, which carries j0 and 4 * hi) is visible iff <= thr
     asm volatile("v_cmp_le_i32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(s[2 * E]) : "v"(thr), "n"(KOFF + crow(2 * E, 0)), "v"(ninf) : "vcc");
     asm volatile("v_cmp_le_i32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(s[2 * E + 1]) : "v"(thr), "n"(KOFF + crow(2 * E + 1, 0)), "v"(ninf) : "vcc");
   }
-  asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[2 * E]));
-  asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[2 * E + 1]));
+  if constexpr ((ABL & 1) != 0) {      // (ablation: a plain VALU instruction instead of the transcendental)
+    asm volatile("v_mul_f32_e32 %0, %0, %0" : "+v"(s[2 * E]));
+    asm volatile("v_mul_f32_e32 %0, %0, %0" : "+v"(s[2 * E + 1]));
+  } else {
+    asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[2 * E]));
+    asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[2 * E + 1]));
+  }
 }
 // RSUM: the row sum takes the ROUNDED pair (v_dot2c against packed ones, like the other 16-bit forward forms: O is then a true convex
 // combination of V rows); else the two un-rounded values (two plain adds)
@@ -112,10 +117,11 @@ template <typename T, bool RSUM, int E> FCSA_DEV void sm_sum_pack(const f32x16& 
 }
 // the share of gap G (0..15) of a phase in the softmax HALF of a block: items 8 * HALF + G / 2 -- row block HALF -- exps in the even gap,
 // sums and pack in the odd one (>= one MFMA between an exp and its consumers)
-template <typename T, bool RSUM, bool MASKED, int HALF, int G, int KOFF>
+template <typename T, bool RSUM, bool MASKED, int HALF, int G, int KOFF, int ABL = 0>
 FCSA_DEV void sm_gap(F3State<T>& st, f32x16 (&s)[2], u32x4 (&pk)[2][2], const int (&thr)[2]) {
   constexpr int E = G >> 1;
-  if constexpr ((G & 1) == 0) sm_exp<MASKED, E, KOFF>(s[HALF], thr[HALF], st.ninf);
+  if constexpr ((ABL & 8) != 0) return;      // (ablation: no softmax work at all)
+  if constexpr ((G & 1) == 0) sm_exp<MASKED, E, KOFF, ABL>(s[HALF], thr[HALF], st.ninf);
   else sm_sum_pack<T, RSUM, E>(s[HALF], pk[HALF], st.l[HALF], st.one2);
 }
 
@@ -129,16 +135,16 @@ FCSA_DEV void addr_step(uint32_t& a, uint32_t delta) { asm volatile("v_add_u32_e
 // S phase of key block KB: 16 MFMAs (k-step outer, row block inner: the two chains alternate), the K fragments of this block were
 // requested during the previous phase.  `filler(g)` = this gap's softmax share; V^T fragments at va + VOFF (key block, 16-key step) are
 // requested two reads per gap in gaps 0..7; `extra(g)` = address steps / DMA pieces of this phase.
-template <typename T, int VOFF, typename Filler, typename Extra>
+template <typename T, int VOFF, int ABL, typename Filler, typename Extra>
 FCSA_DEV void s_phase(F3State<T>& st, f32x16 (&sblk)[2], Filler&& filler, Extra&& extra) {
   static_for<16>([&](auto gc) {
     constexpr int g = decltype(gc)::value, ks = g >> 1, qb = g & 1;
     // K fragment ks has landed: behind it are 7 - ks K reads and the V^T reads this phase has issued so far (LDS reads return in order)
-    if constexpr (qb == 0) wait_lgkm<cmin<15, (7 - ks) + 2 * cmin<g, 8>()>()>();
+    if constexpr (qb == 0 && (ABL & 16) == 0) wait_lgkm<cmin<15, (7 - ks) + 2 * cmin<g, 8>()>()>();
     if constexpr (ks == 0) Ins<T>::s_first(sblk[qb], st.kf[0], st.q[qb][0], st.cinit);
     else Ins<T>::s_next(sblk[qb], st.kf[ks], st.q[qb][ks]);
     filler(gc);
-    if constexpr (g < 8) {      // V^T fragment f = g: (16-key step g / 4, feature block g % 4) -- consumed in that order by the PV phase
+    if constexpr (g < 8 && (ABL & 16) == 0) {      // V^T fragment f = g: (16-key step g / 4, feature block g % 4) -- consumed in that order by the PV phase
       lds_read_vt<VOFF + 16 * (g >> 2) * 256>(st.vf[g], st.va[2 * (g & 3)], st.va[2 * (g & 3) + 1]);
     }
     extra(gc);
@@ -146,45 +152,53 @@ FCSA_DEV void s_phase(F3State<T>& st, f32x16 (&sblk)[2], Filler&& filler, Extra&
 }
 // PV phase of a key block: 16 MFMAs (16-key step outer, feature block, row block inner: a fragment feeds two MFMAs, an accumulator
 // returns after 8).  K fragments at ka + KOFFB are requested one per gap in gaps 0..7.
-template <typename T, int KOFFB, typename Filler, typename Extra>
+template <typename T, int KOFFB, int ABL, typename Filler, typename Extra>
 FCSA_DEV void pv_phase(F3State<T>& st, u32x4 (&pblk)[2][2], Filler&& filler, Extra&& extra) {
   static_for<16>([&](auto gc) {
     constexpr int g = decltype(gc)::value, f = g >> 1, qb = g & 1, ks2 = f >> 2, db = f & 3;
     // V^T fragment f (reads 2f, 2f + 1 of 16) has landed: behind it are 14 - 2f V^T reads and the K reads issued so far
-    if constexpr (qb == 0) wait_lgkm<cmin<15, (14 - 2 * f) + cmin<g, 8>()>()>();
+    if constexpr (qb == 0 && (ABL & 16) == 0) wait_lgkm<cmin<15, (14 - 2 * f) + cmin<g, 8>()>()>();
     Ins<T>::pv(st.o[qb][db], st.vf[f], pblk[qb][ks2]);
     filler(gc);
-    if constexpr (g < 8) lds_read_k<KOFFB>(st.kf[g], st.ka[g]);
+    if constexpr (g < 8 && (ABL & 16) == 0) lds_read_k<KOFFB>(st.kf[g], st.ka[g]);
     extra(gc);
   });
 }
 
 // One tile.  dk_next / dv_next: LDS byte distance from the slot of K(t) to that of K(t+1) (= from V(t-1) to V(t) one tile earlier).
 // thr_prev / thr_cur: per-lane visibility thresholds of the tile whose block 1 is still in flight and of this tile (MASKED only).
-template <typename T, int R, bool RSUM, bool MASKED, typename DmaK, typename DmaV>
-FCSA_DEV void fwd3_tile(F3State<T>& st, uint32_t dk_next, uint32_t dv_next, const int (&thr_prev)[2], const int (&thr_cur)[2], DmaK&& dma_k, DmaV&& dma_v) {
+template <typename T, int R, bool RSUM, bool MASKED, int ABL, typename DmaK, typename DmaV>
+FCSA_DEV void fwd3_tile(F3State<T>& st, Trace& ts, uint32_t dk_next, uint32_t dv_next, const int (&thr_prev)[2], const int (&thr_cur)[2], DmaK&& dma_k, DmaV&& dma_v) {
   auto none = [](auto) {};
   // P1: S0(t) | 2nd half softmax of (t-1, kb 1) | V^T reads of (t-1, kb 1)
-  s_phase<T, 8192>(st, st.s[0], [&](auto gc) { sm_gap<T, RSUM, MASKED, 1, decltype(gc)::value, 32>(st, st.s[1], st.pk[1], thr_prev); }, none);
+  FCSA_STAMP(ts, 0);
+  s_phase<T, 8192, ABL>(st, st.s[0], [&](auto gc) { sm_gap<T, RSUM, MASKED, 1, decltype(gc)::value, 32, ABL>(st, st.s[1], st.pk[1], thr_prev); }, none);
+  FCSA_STAMP(ts, 1);
   // P2: PV1(t-1) | 1st half softmax of (t, kb 0) | K reads of (t, kb 1) | va: V(t-1) -> V(t)
-  pv_phase<T, 8192>(st, st.pk[1], [&](auto gc) { sm_gap<T, RSUM, MASKED, 0, decltype(gc)::value, 0>(st, st.s[0], st.pk[0], thr_cur); },
+  pv_phase<T, 8192, ABL>(st, st.pk[1], [&](auto gc) { sm_gap<T, RSUM, MASKED, 0, decltype(gc)::value, 0, ABL>(st, st.s[0], st.pk[0], thr_cur); },
                     [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8) addr_step(st.va[g - 8], dv_next); });
   // every wave is done with K(t) and V(t-1) -- lgkmcnt(0): its reads of them have RETURNED (the K reads went out >= 8 gaps ago: free),
   // so the DMA behind the barrier cannot overtake a read; the pieces of K(t+1) and V(t) that THIS wave requested have landed
   // (vmcnt: the 8 pieces per period younger than those may stay in flight), the barrier publishes all
-  wait_lgkm<0>();
-  wait_vm<8 * (R - 2)>();
-  wg_barrier();
+  FCSA_STAMP(ts, 2);
+  if constexpr ((ABL & 4) == 0) {
+    wait_lgkm<0>();
+    wait_vm<8 * (R - 2)>();
+    wg_barrier();
+  }
+  FCSA_STAMP(ts, 3);
   // P3: S1(t) | 2nd half softmax of (t, kb 0) | V^T reads of (t, kb 0) | ka: K(t) -> K(t+1) | DMA K(t+R) -> slot of K(t)
-  s_phase<T, 0>(st, st.s[1], [&](auto gc) { sm_gap<T, RSUM, MASKED, 1, decltype(gc)::value, 0>(st, st.s[0], st.pk[0], thr_cur); },
+  s_phase<T, 0, ABL>(st, st.s[1], [&](auto gc) { sm_gap<T, RSUM, MASKED, 1, decltype(gc)::value, 0, ABL>(st, st.s[0], st.pk[0], thr_cur); },
                 [&](auto gc) {
                   constexpr int g = decltype(gc)::value;
                   if constexpr (g >= 8) addr_step(st.ka[g - 8], dk_next);
-                  if constexpr (g >= 8 && (g & 1) == 0) dma_k((g - 8) >> 1);
+                  if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_k((g - 8) >> 1);
                 });
+  FCSA_STAMP(ts, 4);
   // P4: PV0(t) | 1st half softmax of (t, kb 1) | K reads of (t+1, kb 0) | DMA V(t+R-1) -> slot of V(t-1)
-  pv_phase<T, 0>(st, st.pk[0], [&](auto gc) { sm_gap<T, RSUM, MASKED, 0, decltype(gc)::value, 32>(st, st.s[1], st.pk[1], thr_cur); },
-                 [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0) dma_v((g - 8) >> 1); });
+  pv_phase<T, 0, ABL>(st, st.pk[0], [&](auto gc) { sm_gap<T, RSUM, MASKED, 0, decltype(gc)::value, 32, ABL>(st, st.s[1], st.pk[1], thr_cur); },
+                      [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_v((g - 8) >> 1); });
+  FCSA_STAMP(ts, 5);
 }
 
 // After the last tile: 2nd half softmax of its block 1 and PV1 (not overlapped: once per pass).  va points at the last tile's slot.
@@ -204,7 +218,11 @@ FCSA_DEV void fwd3_drain(F3State<T>& st, const int (&thr_last)[2]) {
   asm volatile("s_nop 15\n\ts_nop 15");      // the last MFMA's result, before hipcc's own accumulator reads (it does not see the MFMA)
 }
 
-template <typename T, int R, bool RSUM>
+#ifdef FCSA_TRACE
+__device__ unsigned long long g_trace_fwd3[128];
+#endif
+
+template <typename T, int R, bool RSUM, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
   constexpr int D = 128;
   typedef TileGeom<D, 2> G;
@@ -235,6 +253,11 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
   dv_.init(p.v.sn, wave, lane);
   const uint32_t k_step = (uint32_t)(BN * p.k.sn), v_step = (uint32_t)(BN * p.v.sn);      // (launcher: M * pitch < 2 GiB)
 
+  Trace ts;
+  ts.reset();
+#ifdef FCSA_TRACE
+  const unsigned long long trace_t0 = trace_now();
+#endif
   F3State<T> st;
   {
     // (through an opaque VGPR: as a uniform value hipcc keeps the 16-register tuple in SGPRs and re-materialises it with 8 v_mov_b64 per tile)
@@ -336,7 +359,8 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
         const int j0 = t * BN;
         const int thr_cur[2] = {thr0[0] - j0, thr0[1] - j0};
         const int thr_prev[2] = {thr_cur[0] + BN, thr_cur[1] + BN};
-        fwd3_tile<T, R, RSUM, MASKED>(st, dk_next, dv_next, thr_prev, thr_cur, dma_k, dma_v);
+        fwd3_tile<T, R, RSUM, MASKED, ABL>(st, ts, dk_next, dv_next, thr_prev, thr_cur, dma_k, dma_v);
+        if constexpr (!MASKED) ts.close(5);
         stk.off += k_step;
         stv.off += v_step;
         slot = slot + 1 == R ? 0 : slot + 1;
@@ -371,18 +395,28 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
       wg_barrier();              // the scratch is free again before the next pass's DMA overwrites it
     }
   }   // pass
+#ifdef FCSA_TRACE
+  if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) ts.dump(g_trace_fwd3 + 32 * wave, trace_now() - trace_t0);
+#endif
 }
+#ifdef FCSA_TRACE
+}  // namespace fcsa
+extern "C" int fcsa_trace_read_fwd3(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcsa::g_trace_fwd3), sizeof(unsigned long long) * 128);
+}
+namespace fcsa {
+#endif
 
 constexpr int kFwd3Ring = 3;             // K and V ring depth (tiles): 96 KiB of the CU's 160
 constexpr bool kFwd3RoundedSums = false; // row sums of the un-rounded P~ (two adds) or of the rounded pair (v_dot2c)
 
-template <typename T, int R, bool RSUM>
+template <typename T, int R, bool RSUM, int ABL = 0>
 static hipError_t launch_fwd3_t(const FwdParams& p, hipStream_t s) {
   const int MT = (p.N + 255) / 256;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   size_t lds = (size_t)2 * R * 16384;
   if (lds < (size_t)4 * RowEpilogue<T, 128>::BYTES_NOX) lds = (size_t)4 * RowEpilogue<T, 128>::BYTES_NOX;
-  auto kern = fwd3_kernel<T, R, RSUM>;
+  auto kern = fwd3_kernel<T, R, RSUM, ABL>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(256), lds, s, p);
@@ -410,6 +444,12 @@ static hipError_t launch_fwd3_v(const FwdParams& p, hipStream_t s) {
     if (e[1] == '2') return d ? launch_fwd3_t<T, 2, true>(p, s) : launch_fwd3_t<T, 2, false>(p, s);
     if (e[1] == '3') return d ? launch_fwd3_t<T, 3, true>(p, s) : launch_fwd3_t<T, 3, false>(p, s);
     if (e[1] == '4') return d ? launch_fwd3_t<T, 4, true>(p, s) : launch_fwd3_t<T, 4, false>(p, s);
+    if (e[1] == 'x') return launch_fwd3_t<T, 3, false, 1>(p, s);       // ablations (wrong results, timing only): exp -> mul
+    if (e[1] == 'y') return launch_fwd3_t<T, 3, false, 2>(p, s);       //   no DMA in the loop
+    if (e[1] == 'z') return launch_fwd3_t<T, 3, false, 4>(p, s);       //   no waits / barrier between P2 and P3
+    if (e[1] == 'w') return launch_fwd3_t<T, 3, false, 8>(p, s);       //   no softmax VALU work
+    if (e[1] == 'v') return launch_fwd3_t<T, 3, false, 16>(p, s);      //   no LDS reads
+    if (e[1] == 'u') return launch_fwd3_t<T, 3, false, 30>(p, s);      //   MFMAs only
   }
 #endif
   return launch_fwd3_t<T, kFwd3Ring, kFwd3RoundedSums>(p, s);

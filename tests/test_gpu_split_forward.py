@@ -66,7 +66,7 @@ def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv,
     rdq, rdk, rdv, _ = O.attention_backward(_npf(do), _npf(q), _npf(k), _npf(v), **kw)
     for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
         rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
-        assert T.check("split/grad rel-L2", dtype, rel, GRAD_TOL[dtype]), f"{name} rel-L2 {rel:.3e}"
+        assert T.check("split/grad rel-L2", dtype, rel, GRAD_TOL[dtype] * T.SPLIT_GRAD_FACTOR[dtype]), f"{name} rel-L2 {rel:.3e}"
 
 
 def test_split_and_unsplit_agree_through_the_c_abi():
@@ -147,4 +147,4 @@ def test_split_query_dkv_matches_oracle(dtype, B, H, N, M, D, use_mask, l2norm, 
     for name, got, ref in (("dq", q.grad, rdq), ("dk", k.grad, rdk), ("dv", v.grad, rdv)):
         assert torch.isfinite(got).all(), name
         rel = np.linalg.norm(_npf(got) - ref) / max(np.linalg.norm(ref), 1e-3 * np.sqrt(ref.size))
-        assert T.check("split/grad rel-L2", dtype, rel, GRAD_TOL[dtype]), f"{name} rel-L2 {rel:.3e}"
+        assert T.check("split/grad rel-L2", dtype, rel, GRAD_TOL[dtype] * T.SPLIT_GRAD_FACTOR[dtype]), f"{name} rel-L2 {rel:.3e}"

@@ -16,8 +16,17 @@ import json
 import os
 
 #            atol,  rtol (one output ulp), rel-L2 of the forward output
-FWD_TOL = {"f16": (5e-3, 2.0 ** -10, 1e-3), "bf16": (2e-2, 2.0 ** -7, 5e-3), "f32": (2e-5, 2e-5, 1e-5)}
-GRAD_TOL = {"f16": 3e-3, "bf16": 1.2e-2, "f32": 2e-5}
+# Round 5 calibration (profiles/r05_tolerance_margins.txt, all 1531 GPU tests logged): worst measured over the suite ->
+#   forward rel-L2   bf16 4.09e-3 (x_n200_d16_causal: D = 16, 200 keys)   f16 5.74e-4   f32 2.13e-6
+#   forward excess   bf16 0.75 of the bar   f16 1.56e-3 (of 5e-3)   f32 6.3e-6 (of 2e-5)
+#   gradient rel-L2  bf16 5.8e-3 (K28 D = 16 causal; 5.2e-3 on the reference grid)   f16 9.0e-4   f32 2.0e-6 (2.4e-5 at scale 120, its own bar)
+# (rounds 1 - 4: bf16 gradients 1.2e-2, f16 3e-3 / forward 5e-3 abs, 1e-3 rel -- 2 - 3x what the kernels do; a regression that doubled
+#  the gradient error would have passed)
+FWD_TOL = {"f16": (2.5e-3, 2.0 ** -10, 8.5e-4), "bf16": (2e-2, 2.0 ** -7, 4.5e-3), "f32": (1e-5, 2e-5, 4e-6)}
+GRAD_TOL = {"f16": 1.4e-3, "bf16": 8.5e-3, "f32": 2e-5}
+# the split-key / split-query forms sum partial f32 slabs of a FEW keys / queries each: their bf16 gradients measured 7.7e-3 on the
+# smallest splits (tests/test_gpu_split_forward.py), f16 / f32 like everywhere else
+SPLIT_GRAD_FACTOR = {"f16": 1.0, "bf16": 1.4, "f32": 1.0}
 
 _LOG = os.environ.get("FCSA_TOL_LOG")
 

@@ -9,13 +9,23 @@ for step in "$@"; do
       rm -f gpurun_out/tol_log0.jsonl
       FCSA_FWD_WIDE128=0 FCSA_TOL_LOG=$PWD/gpurun_out/tol_log0.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=200 -p no:cacheprovider --deselect tests/test_gpu_wide128.py > gpurun_out/pytest_suite0.log 2>&1
       tail -n 15 gpurun_out/pytest_suite0.log | cut -c1-300 ;;
+    canary)   # one small launch of the new kernel under a short timeout: a hang here switches the new form off for the rest of the session
+      timeout 240 python -m pytest tests/test_gpu_wide128.py -m gpu -q -x -k "causal_square or full_one_tile" -p no:cacheprovider > gpurun_out/pytest_canary.log 2>&1
+      rc=$?; tail -n 25 gpurun_out/pytest_canary.log | cut -c1-400
+      if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "CANARY TIMED OUT: disabling the wide form"; export FCSA_FWD_WIDE128=0; export FCSA_CANARY_FAILED=1; fi ;;
     wide)     # the new kernel's own tests
+      if [ -n "${FCSA_CANARY_FAILED:-}" ]; then echo "skipped (canary)"; continue; fi
       rm -f gpurun_out/tol_log_wide.jsonl
       FCSA_TOL_LOG=$PWD/gpurun_out/tol_log_wide.jsonl timeout 900 python -m pytest tests/test_gpu_wide128.py tests/test_gpu_wide_forward.py -m gpu -q --maxfail=100 -p no:cacheprovider > gpurun_out/pytest_wide.log 2>&1
       tail -n 40 gpurun_out/pytest_wide.log | cut -c1-400 ;;
     ab)
+      if [ -n "${FCSA_CANARY_FAILED:-}" ]; then echo "skipped (canary)"; continue; fi
       timeout 600 python tools/fwd3_ab.py --variants 0 r2 r3 r4 r3d r2d > gpurun_out/fwd3_ab.txt 2>&1; cat gpurun_out/fwd3_ab.txt
       timeout 300 python tools/fwd3_ab.py --dtype f16 --shapes 4,8,4096,4096,1 --variants 0 r3 r3d > gpurun_out/fwd3_ab_f16.txt 2>&1; cat gpurun_out/fwd3_ab_f16.txt ;;
+    abl)      # ablations of the wide form's tile loop (development build of the library: wrong results, timing only) + phase trace
+      timeout 600 python tools/fwd3_ab.py --shapes 4,8,4096,4096,0 4,8,4096,4096,1 --variants 0 r3 rx ry rz rw rv ru --rounds 3 > gpurun_out/fwd3_abl.txt 2>&1; cat gpurun_out/fwd3_abl.txt
+      FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 0 > gpurun_out/trace_fwd3.txt 2>&1
+      FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 1 >> gpurun_out/trace_fwd3.txt 2>&1; cat gpurun_out/trace_fwd3.txt ;;
     suite)    # the whole GPU suite as shipped
       rm -f gpurun_out/tol_log.jsonl
       FCSA_TOL_LOG=$PWD/gpurun_out/tol_log.jsonl timeout 1800 python -m pytest tests -m gpu -q --maxfail=200 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
