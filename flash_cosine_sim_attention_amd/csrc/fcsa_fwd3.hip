@@ -21,13 +21,13 @@
 // phases of 16 MFMAs; the exp / row-sum / pack work of a block (80 VALU instructions) is spread over the 32 MFMAs that follow its S
 // chain, the LDS reads of the next phase's fragments and the LDS-DMA of later tiles ride in the same gaps:
 //
-//     P1  S0(t)    | softmax 2nd half of block 1 of tile t-1 | V^T reads of (t-1, kb 1)
-//     P2  PV1(t-1) | softmax 1st half of block 0 of tile t   | K reads of (t, kb 1)
-//     --  s_waitcnt vmcnt(8 (R - 2)); s_barrier  (every wave is done with K(t) and V(t-1); K(t+1) and V(t) are visible)
-//     P3  S1(t)    | softmax 2nd half of block 0 of tile t   | V^T reads of (t, kb 0)   | LDS-DMA K(t+R)   -> slot of K(t)
-//     P4  PV0(t)   | softmax 1st half of block 1 of tile t   | K reads of (t+1, kb 0)   | LDS-DMA V(t+R-1) -> slot of V(t-1)
+//     P1  S0(t)    | softmax of (t-1, kb 1, rows 32..63) | V^T reads of (t-1, kb 1)
+//     P2  PV1(t-1) | softmax of (t, kb 0, rows 0..31)    | K reads of (t, kb 1)     | LDS-DMA K(t+R-1) -> slot of K(t-1)
+//     --  s_waitcnt lgkmcnt(0) vmcnt(8 (R - 3) + 4); s_barrier  (every wave is done with K(t) and V(t-1); K(t+1) and V(t) are visible)
+//     P3  S1(t)    | softmax of (t, kb 0, rows 32..63)   | V^T reads of (t, kb 0)
+//     P4  PV0(t)   | softmax of (t, kb 1, rows 0..31)    | K reads of (t+1, kb 0)   | LDS-DMA V(t+R-2) -> slot of V(t-2)
 //
-// i.e. <= 5 fillers per MFMA gap (1 - 2 exp, 1 - 2 add, <= 1 cvt_pk, <= 2 LDS reads or one DMA piece), one barrier per tile, rings of
+// i.e. <= 5 fillers per MFMA gap (one exp, one add, a cvt_pk every other gap, <= 2 LDS reads or an address step / DMA piece), one barrier per tile, rings of
 // R tiles for K and for V.  Row sums are plain f32 adds of the un-rounded P~ (four partial sums per row pair: v_dot2c on the packed
 // values costs more than two adds beside MFMAs, MI355X guide "price of one filler").  Tiles that need masking for a wave (the causal
 // diagonal, a ragged last tile) run a second instantiation of the same body with a compare + select in front of each exp.
@@ -63,12 +63,11 @@ FCSA_INS(F16, "v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32", "v_dot2c_f32_f16_e3
 #undef FCSA_INS
 
 template <int OFF> FCSA_DEV void lds_read_k(u32x4& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "i"(OFF)); }
-template <int OFF> FCSA_DEV void lds_read_vt(u32x4& d, uint32_t a0, uint32_t a1) {      // the two 4-row halves of a transposed fragment
-  u32x2 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(OFF));
-  d[0] = lo[0]; d[1] = lo[1]; d[2] = hi[0]; d[3] = hi[1];
+// one 4-row half of a transposed fragment (registers 2 HALF, 2 HALF + 1 of the MFMA operand)
+template <int OFF, int HALF> FCSA_DEV void lds_read_vt_half(u32x2 (&d)[2], uint32_t a) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d[HALF]) : "v"(a), "i"(OFF));
 }
+FCSA_DEV u32x4 vt_frag(const u32x2 (&h)[2]) { u32x4 d; d[0] = h[0][0]; d[1] = h[0][1]; d[2] = h[1][0]; d[3] = h[1][1]; return d; }
 template <int N> FCSA_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> FCSA_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 FCSA_DEV void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -80,7 +79,7 @@ template <typename T> struct F3State {
   u32x4 kf[8];           // "a"  K fragments of ONE 32-key block [k-step] (both row blocks use each one)
   f32x16 s[2][2];        // "v"  logits -> P~ [key block][row block]
   u32x4 pk[2][2][2];     // "v"  packed P~ [key block][row block][16-key step]
-  u32x4 vf[8];           // "v"  V^T fragments of one 32-key block [16-key step * 4 + feature block]
+  u32x2 vfh[8][2];       // "v"  V^T fragments of one 32-key block [16-key step * 4 + feature block][4-row half]
   f32x16 cinit;          // "v"  -shift in all 16 registers: the C operand of every S chain's first k-step
   float l[2][2];         // "v"  row-sum partials [row block][even / odd register]
   float ninf;            // "v"  -inf (select operand of the masked tiles)
@@ -89,43 +88,54 @@ template <typename T> struct F3State {
   uint32_t va[8];        //      LDS byte address of this lane's transposed-read rows per (feature block, half) (slot 0, key step 0)
 };
 
-// softmax item E (0..7) of one [32 keys x 32 rows] block = accumulator registers 2E, 2E + 1: (select,) exp | add, pack
-template <bool MASKED, int E, int KOFF, int ABL = 0> FCSA_DEV void sm_exp(f32x16& s, int thr, float ninf) {
+// Softmax of one [32 keys x 32 rows] block half (= one row block's 16 accumulator registers), spread over the 16 MFMA gaps of a phase
+// with ONE transcendental per gap (v_exp_f32 issues at quarter rate: two in one gap were 32 of its 32 matrix cycles):
+//     gap G:  (select,) exp of register G  |  row-sum add of register G - 1  |  even G >= 2: pack of registers G - 2, G - 1
+// so every consumer sits one MFMA behind its producer, and the tail -- the add of register 15 and the pack of registers 14, 15 -- is the
+// head of the NEXT phase's gap 0 (`sm_tail`), whatever block half that phase works on.
+template <bool MASKED, int R_, int KOFF, int ABL> FCSA_DEV void sm_exp1(f32x16& s, int thr, float ninf) {
   if constexpr (MASKED) {      // key row KOFF + crow(r, 0) (relative to this lane's threshold, which carries j0 and 4 * hi) is visible iff <= thr
-    asm volatile("v_cmp_le_i32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(s[2 * E]) : "v"(thr), "n"(KOFF + crow(2 * E, 0)), "v"(ninf) : "vcc");
-    asm volatile("v_cmp_le_i32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(s[2 * E + 1]) : "v"(thr), "n"(KOFF + crow(2 * E + 1, 0)), "v"(ninf) : "vcc");
+    asm volatile("v_cmp_le_i32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(s[R_]) : "v"(thr), "n"(KOFF + crow(R_, 0)), "v"(ninf) : "vcc");
   }
-  if constexpr ((ABL & 1) != 0) {      // (ablation: a plain VALU instruction instead of the transcendental)
-    asm volatile("v_mul_f32_e32 %0, %0, %0" : "+v"(s[2 * E]));
-    asm volatile("v_mul_f32_e32 %0, %0, %0" : "+v"(s[2 * E + 1]));
-  } else {
-    asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[2 * E]));
-    asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[2 * E + 1]));
-  }
+  if constexpr ((ABL & 1) != 0) asm volatile("v_mul_f32_e32 %0, %0, %0" : "+v"(s[R_]));      // (ablation: a plain VALU instruction)
+  else asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[R_]));
 }
 // RSUM: the row sum takes the ROUNDED pair (v_dot2c against packed ones, like the other 16-bit forward forms: O is then a true convex
-// combination of V rows); else the two un-rounded values (two plain adds)
-template <typename T, bool RSUM, int E> FCSA_DEV void sm_sum_pack(const f32x16& s, u32x4 (&pk)[2], float (&l)[2], uint32_t one2) {
-  if constexpr (!RSUM) {
-    asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(l[0]) : "v"(s[2 * E]));
-    asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(l[1]) : "v"(s[2 * E + 1]));
-  }
+// combination of V rows); else the un-rounded values (plain adds, two partial sums per row block)
+template <bool RSUM, int R_> FCSA_DEV void sm_add1(const f32x16& s, float (&l)[2]) {
+  if constexpr (!RSUM) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(l[R_ & 1]) : "v"(s[R_]));
+}
+template <typename T, bool RSUM, int E> FCSA_DEV void sm_pack1(const f32x16& s, u32x4 (&pk)[2], float (&l)[2], uint32_t one2) {
   uint32_t u;
   Ins<T>::cvt_pk(u, s[2 * E], s[2 * E + 1]);
   if constexpr (RSUM) Ins<T>::add_pair(l[E & 1], u, one2);
   pk[E >> 2][E & 3] = u;
 }
-// the share of gap G (0..15) of a phase in the softmax HALF of a block: items 8 * HALF + G / 2 -- row block HALF -- exps in the even gap,
-// sums and pack in the odd one (>= one MFMA between an exp and its consumers)
 template <typename T, bool RSUM, bool MASKED, int HALF, int G, int KOFF, int ABL = 0>
 FCSA_DEV void sm_gap(F3State<T>& st, f32x16 (&s)[2], u32x4 (&pk)[2][2], const int (&thr)[2]) {
-  constexpr int E = G >> 1;
   if constexpr ((ABL & 8) != 0) return;      // (ablation: no softmax work at all)
-  if constexpr ((G & 1) == 0) sm_exp<MASKED, E, KOFF, ABL>(s[HALF], thr[HALF], st.ninf);
-  else sm_sum_pack<T, RSUM, E>(s[HALF], pk[HALF], st.l[HALF], st.one2);
+  if constexpr (G >= 1) sm_add1<RSUM, G - 1>(s[HALF], st.l[HALF]);
+  sm_exp1<MASKED, G, KOFF, ABL>(s[HALF], thr[HALF], st.ninf);
+  if constexpr (G >= 2 && (G & 1) == 0) sm_pack1<T, RSUM, (G - 2) / 2>(s[HALF], pk[HALF], st.l[HALF], st.one2);
+}
+// the tail of the block half the PREVIOUS phase worked on
+template <typename T, bool RSUM, int HALF, int ABL = 0>
+FCSA_DEV void sm_tail(F3State<T>& st, f32x16 (&s)[2], u32x4 (&pk)[2][2]) {
+  if constexpr ((ABL & 8) != 0) return;
+  sm_add1<RSUM, 15>(s[HALF], st.l[HALF]);
+  sm_pack1<T, RSUM, 7>(s[HALF], pk[HALF], st.l[HALF], st.one2);
 }
 
 template <int A, int B> constexpr int cmin() { return A < B ? A : B; }
+// One LDS-DMA piece inside the tile loop: M0 <- LDS byte address of the piece (wave-uniform), 64 x 16 bytes from `rs` at per-lane
+// byte offset voff + wave-uniform soff.  M0 is clobbered, not saved (guide 5.7): three instructions instead of DmaStager::issue_piece's
+// six plus its per-call descriptor shuffle -- the pieces are the most expensive fillers of the loop (45 ... 90 ticks each, trace).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (the M0 clobber is deliberate: see above)
+FCSA_DEV void dma_piece(uint32_t lds_dst, uint32_t voff, const u32x4& rs, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 FCSA_DEV void addr_step(uint32_t& a, uint32_t delta) { asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(a) : "s"(delta)); }
 
 // The ring slot of a tile is a RUN-TIME quantity carried in the 16 LDS address registers (ka: slot of K(t), stepped to K(t+1) during P3;
@@ -144,8 +154,11 @@ FCSA_DEV void s_phase(F3State<T>& st, f32x16 (&sblk)[2], Filler&& filler, Extra&
     if constexpr (ks == 0) Ins<T>::s_first(sblk[qb], st.kf[0], st.q[qb][0], st.cinit);
     else Ins<T>::s_next(sblk[qb], st.kf[ks], st.q[qb][ks]);
     filler(gc);
-    if constexpr (g < 8 && (ABL & 16) == 0) {      // V^T fragment f = g: (16-key step g / 4, feature block g % 4) -- consumed in that order by the PV phase
-      lds_read_vt<VOFF + 16 * (g >> 2) * 256>(st.vf[g], st.va[2 * (g & 3)], st.va[2 * (g & 3) + 1]);
+    // V^T fragment f = g in the first eight gaps, both halves: (16-key step f / 4, feature block f % 4) -- consumed in that order by the PV
+    // phase.  (One read per gap over all sixteen gaps measured +90 ticks per S phase: profiles/r05_fwd3_trace_v4.txt.)
+    if constexpr (g < 8 && (ABL & 16) == 0) {
+      lds_read_vt_half<VOFF + 16 * (g >> 2) * 256, 0>(st.vfh[g], st.va[2 * (g & 3)]);
+      lds_read_vt_half<VOFF + 16 * (g >> 2) * 256, 1>(st.vfh[g], st.va[2 * (g & 3) + 1]);
     }
     extra(gc);
   });
@@ -158,7 +171,7 @@ FCSA_DEV void pv_phase(F3State<T>& st, u32x4 (&pblk)[2][2], Filler&& filler, Ext
     constexpr int g = decltype(gc)::value, f = g >> 1, qb = g & 1, ks2 = f >> 2, db = f & 3;
     // V^T fragment f (reads 2f, 2f + 1 of 16) has landed: behind it are 14 - 2f V^T reads and the K reads issued so far
     if constexpr (qb == 0 && (ABL & 16) == 0) wait_lgkm<cmin<15, (14 - 2 * f) + cmin<g, 8>()>()>();
-    Ins<T>::pv(st.o[qb][db], st.vf[f], pblk[qb][ks2]);
+    Ins<T>::pv(st.o[qb][db], vt_frag(st.vfh[f]), pblk[qb][ks2]);
     filler(gc);
     if constexpr (g < 8 && (ABL & 16) == 0) lds_read_k<KOFFB>(st.kf[g], st.ka[g]);
     extra(gc);
@@ -167,55 +180,152 @@ FCSA_DEV void pv_phase(F3State<T>& st, u32x4 (&pblk)[2][2], Filler&& filler, Ext
 
 // One tile.  dk_next / dv_next: LDS byte distance from the slot of K(t) to that of K(t+1) (= from V(t-1) to V(t) one tile earlier).
 // thr_prev / thr_cur: per-lane visibility thresholds of the tile whose block 1 is still in flight and of this tile (MASKED only).
+// The LDS-DMA pieces ride in the PV phases (a piece costs ~45 ticks there, ~90 beside the 16 transposed reads of an S phase): K(t+R-1)
+// into the slot of K(t-1) during P2, V(t+R-2) into the slot of V(t-2) during P4 -- both slots were released by the PREVIOUS tile's barrier.
 template <typename T, int R, bool RSUM, bool MASKED, int ABL, typename DmaK, typename DmaV>
 FCSA_DEV void fwd3_tile(F3State<T>& st, Trace& ts, uint32_t dk_next, uint32_t dv_next, const int (&thr_prev)[2], const int (&thr_cur)[2], DmaK&& dma_k, DmaV&& dma_v) {
-  auto none = [](auto) {};
-  // P1: S0(t) | 2nd half softmax of (t-1, kb 1) | V^T reads of (t-1, kb 1)
+  // P1: S0(t) | softmax of (t-1, kb 1, rows 32..63) [tail of (t-1, kb 1, rows 0..31)] | V^T reads of (t-1, kb 1) | va: V(t-1) -> V(t)
   FCSA_STAMP(ts, 0);
-  s_phase<T, 8192, ABL>(st, st.s[0], [&](auto gc) { sm_gap<T, RSUM, MASKED, 1, decltype(gc)::value, 32, ABL>(st, st.s[1], st.pk[1], thr_prev); }, none);
+  s_phase<T, 8192, ABL>(st, st.s[0],
+                        [&](auto gc) {
+                          constexpr int g = decltype(gc)::value;
+                          if constexpr (g == 0) sm_tail<T, RSUM, 0, ABL>(st, st.s[1], st.pk[1]);
+                          sm_gap<T, RSUM, MASKED, 1, g, 32, ABL>(st, st.s[1], st.pk[1], thr_prev);
+                        },
+                        [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8) addr_step(st.va[g - 8], dv_next); });
   FCSA_STAMP(ts, 1);
-  // P2: PV1(t-1) | 1st half softmax of (t, kb 0) | K reads of (t, kb 1) | va: V(t-1) -> V(t)
-  pv_phase<T, 8192, ABL>(st, st.pk[1], [&](auto gc) { sm_gap<T, RSUM, MASKED, 0, decltype(gc)::value, 0, ABL>(st, st.s[0], st.pk[0], thr_cur); },
-                    [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8) addr_step(st.va[g - 8], dv_next); });
-  // every wave is done with K(t) and V(t-1) -- lgkmcnt(0): its reads of them have RETURNED (the K reads went out >= 8 gaps ago: free),
-  // so the DMA behind the barrier cannot overtake a read; the pieces of K(t+1) and V(t) that THIS wave requested have landed
-  // (vmcnt: the 8 pieces per period younger than those may stay in flight), the barrier publishes all
+  // P2: PV1(t-1) | softmax of (t, kb 0, rows 0..31) [tail of (t-1, kb 1, rows 32..63)] | K reads of (t, kb 1) | DMA K(t+R-1)
+  pv_phase<T, 8192, ABL>(st, st.pk[1],
+                         [&](auto gc) {
+                           constexpr int g = decltype(gc)::value;
+                           if constexpr (g == 0) sm_tail<T, RSUM, 1, ABL>(st, st.s[1], st.pk[1]);
+                           sm_gap<T, RSUM, MASKED, 0, g, 0, ABL>(st, st.s[0], st.pk[0], thr_cur);
+                         },
+                         [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_k((g - 8) >> 1); });
   FCSA_STAMP(ts, 2);
+  // every wave is done with K(t) and V(t-1) -- lgkmcnt(0): its reads of them have RETURNED (the K reads went out >= 8 gaps ago: free),
+  // so a DMA behind the barrier cannot overtake a read; the pieces of K(t+1) and V(t) that THIS wave requested have landed (vmcnt: the
+  // 8 pieces of every younger period and the 4 of this P2 may stay in flight), the barrier publishes all
   if constexpr ((ABL & 4) == 0) {
     wait_lgkm<0>();
-    wait_vm<8 * (R - 2)>();
+    wait_vm<8 * (R - 3) + 4>();
     wg_barrier();
   }
   FCSA_STAMP(ts, 3);
-  // P3: S1(t) | 2nd half softmax of (t, kb 0) | V^T reads of (t, kb 0) | ka: K(t) -> K(t+1) | DMA K(t+R) -> slot of K(t)
-  s_phase<T, 0, ABL>(st, st.s[1], [&](auto gc) { sm_gap<T, RSUM, MASKED, 1, decltype(gc)::value, 0, ABL>(st, st.s[0], st.pk[0], thr_cur); },
-                [&](auto gc) {
-                  constexpr int g = decltype(gc)::value;
-                  if constexpr (g >= 8) addr_step(st.ka[g - 8], dk_next);
-                  if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_k((g - 8) >> 1);
-                });
+  // P3: S1(t) | softmax of (t, kb 0, rows 32..63) [tail of (t, kb 0, rows 0..31)] | V^T reads of (t, kb 0) | ka: K(t) -> K(t+1)
+  s_phase<T, 0, ABL>(st, st.s[1],
+                     [&](auto gc) {
+                       constexpr int g = decltype(gc)::value;
+                       if constexpr (g == 0) sm_tail<T, RSUM, 0, ABL>(st, st.s[0], st.pk[0]);
+                       sm_gap<T, RSUM, MASKED, 1, g, 0, ABL>(st, st.s[0], st.pk[0], thr_cur);
+                     },
+                     [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8) addr_step(st.ka[g - 8], dk_next); });
   FCSA_STAMP(ts, 4);
-  // P4: PV0(t) | 1st half softmax of (t, kb 1) | K reads of (t+1, kb 0) | DMA V(t+R-1) -> slot of V(t-1)
-  pv_phase<T, 0, ABL>(st, st.pk[0], [&](auto gc) { sm_gap<T, RSUM, MASKED, 0, decltype(gc)::value, 32, ABL>(st, st.s[1], st.pk[1], thr_cur); },
+  // P4: PV0(t) | softmax of (t, kb 1, rows 0..31) [tail of (t, kb 0, rows 32..63)] | K reads of (t+1, kb 0) | DMA V(t+R-2)
+  pv_phase<T, 0, ABL>(st, st.pk[0],
+                      [&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        if constexpr (g == 0) sm_tail<T, RSUM, 1, ABL>(st, st.s[0], st.pk[0]);
+                        sm_gap<T, RSUM, MASKED, 0, g, 32, ABL>(st, st.s[1], st.pk[1], thr_cur);
+                      },
                       [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_v((g - 8) >> 1); });
   FCSA_STAMP(ts, 5);
 }
 
-// After the last tile: 2nd half softmax of its block 1 and PV1 (not overlapped: once per pass).  va points at the last tile's slot.
+// After the last tile: the rest of its block 1 (tail of rows 0..31, rows 32..63) and PV1 (not overlapped: once per pass).  va points at
+// the last tile's slot.
 template <typename T, bool RSUM>
 FCSA_DEV void fwd3_drain(F3State<T>& st, const int (&thr_last)[2]) {
   static_for<8>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
-    lds_read_vt<8192 + 16 * (g >> 2) * 256>(st.vf[g], st.va[2 * (g & 3)], st.va[2 * (g & 3) + 1]);
+    lds_read_vt_half<8192 + 16 * (g >> 2) * 256, 0>(st.vfh[g], st.va[2 * (g & 3)]);
+    lds_read_vt_half<8192 + 16 * (g >> 2) * 256, 1>(st.vfh[g], st.va[2 * (g & 3) + 1]);
   });
-  static_for<16>([&](auto gc) { sm_gap<T, RSUM, true, 1, decltype(gc)::value, 32>(st, st.s[1], st.pk[1], thr_last); });
+  sm_tail<T, RSUM, 0>(st, st.s[1], st.pk[1]);
+  static_for<16>([&](auto gc) {
+    sm_gap<T, RSUM, true, 1, decltype(gc)::value, 32>(st, st.s[1], st.pk[1], thr_last);
+    asm volatile("s_nop 1");      // (no MFMA between a v_exp and its consumer here: the transcendental's forwarding gap)
+  });
+  asm volatile("s_nop 1");
+  sm_tail<T, RSUM, 1>(st, st.s[1], st.pk[1]);
   wait_lgkm<0>();
   asm volatile("s_nop 4");      // (the last v_cvt_pk -> MFMA operand)
   static_for<16>([&](auto gc) {
     constexpr int g = decltype(gc)::value, f = g >> 1, qb = g & 1;
-    Ins<T>::pv(st.o[qb][f & 3], st.vf[f], st.pk[1][qb][f >> 2]);
+    Ins<T>::pv(st.o[qb][f & 3], vt_frag(st.vfh[f]), st.pk[1][qb][f >> 2]);
   });
   asm volatile("s_nop 15\n\ts_nop 15");      // the last MFMA's result, before hipcc's own accumulator reads (it does not see the MFMA)
+}
+
+// ---- query rows ------------------------------------------------------------------------------------------------------------------
+// The 64 query rows of a wave as B operands: lane (x, hi) holds the 16-byte chunks 2 kk + hi of rows i0 + x and i0 + 32 + x.  The rows
+// are requested FIRST, by buffer loads inside asm statements (rows >= N read as zero through the descriptor's range check), the ring's
+// first tiles behind them, and ONE counted wait -- vmcnt(number of DMA pieces) -- hands the rows over while the tiles are still in
+// flight: the l2norm arithmetic below then runs under their latency.  (With compiler-visible loads hipcc's own wait for them counts only
+// ITS loads, sees none outstanding behind them, and drains the younger DMA pieces as well: the phase trace showed 17.4 k ticks between
+// "tiles requested" and "c1 * q^ ready", per pass, of which the arithmetic is a quarter.)
+template <int OFF, bool FIRST> FCSA_DEV void q_load(u32x4& d, uint32_t voff, const u32x4& rs) {
+  // (FIRST: the descriptor's SGPRs may be fresh from v_readfirstlane -- five wait states before a buffer instruction reads them, inside
+  //  the statement: hipcc does not pad what it cannot see)
+  if constexpr (FIRST) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(d) : "v"(voff), "s"(rs), "i"(OFF));
+  else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(d) : "v"(voff), "s"(rs), "i"(OFF));
+}
+template <int N> FCSA_DEV void q_wait(u32x4 (&q)[2][8]) {      // every destination is named, so no use of it moves above the wait
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[0][4]), "+v"(q[0][5]), "+v"(q[0][6]), "+v"(q[0][7]) : "n"(N));
+  asm volatile("" : "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]), "+v"(q[1][4]), "+v"(q[1][5]), "+v"(q[1][6]), "+v"(q[1][7]));
+}
+FCSA_DEV float xhalf_sum_swap(float x) {      // x(lane) + x(lane ^ 32) on the VALU (v_permlane32_swap): no LDS round trip in the prologue
+  const uint32_t bits = __builtin_bit_cast(uint32_t, x);
+  const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+  return __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+}
+// raw rows -> c1 * q^ (grouped l2norm fused, the saved state of the backward published), or the plain c1 scaling: the arithmetic of
+// finish_q_frags (fcsa_common.cuh) with the same summation order -- group sums over increasing k-steps -- but one reciprocal norm per
+// GROUP instead of per k-step (a wave-uniform case split on the group size) and the lane-pair sum on the VALU.
+template <typename T>
+FCSA_DEV void fwd3_finish_q(const FwdParams& p, int b, int h, int i, int hi_, u32x4 (&qf)[8]) {
+  constexpr int D = 128;
+  if (p.q_raw) {
+    float pr[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float ss = dot_frag<T>(qf[kk], qf[kk]);
+      pr[kk] = p.lgm >= 1 ? xhalf_sum_swap(ss) : ss;      // groups of >= 16 features contain both chunks of a k-step
+    }
+    const int sh = p.lgm >= 1 ? p.lgm - 1 : 0;            // k-steps per group = 1 << sh
+    auto rn = [&](float tot) { return 1.f / fmaxf(sqrtf(tot), p.norm_eps); };
+    float r[8];
+    if (sh >= 3) {
+      const float v = rn(((((((pr[0] + pr[1]) + pr[2]) + pr[3]) + pr[4]) + pr[5]) + pr[6]) + pr[7]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) r[kk] = v;
+    } else if (sh == 2) {
+      const float v0 = rn(((pr[0] + pr[1]) + pr[2]) + pr[3]), v1 = rn(((pr[4] + pr[5]) + pr[6]) + pr[7]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) r[kk] = kk < 4 ? v0 : v1;
+    } else if (sh == 1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const float v = rn(pr[2 * g] + pr[2 * g + 1]); r[2 * g] = v; r[2 * g + 1] = v; }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) r[kk] = rn(pr[kk]);
+    }
+    const int64_t row = ((int64_t)b * p.H + h) * p.N + i;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      qf[kk] = scale_frag<T>(qf[kk], r[kk] * p.c1);
+      if (i < p.N) {
+        const int c = 2 * kk + hi_;
+        if (p.qn_out != nullptr) *reinterpret_cast<u32x4*>(p.qn_out + (row * D + 8 * c) * 2) = qf[kk];      // (inference: nothing is saved)
+        if (p.rq_out != nullptr && (c & ((1 << p.lgm) - 1)) == 0) p.rq_out[row * p.G + (c >> p.lgm)] = r[kk];
+      }
+    }
+    return;
+  }
+  if (!p.q_scaled) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = scale_frag<T>(qf[kk], p.c1);
+  }
 }
 
 #ifdef FCSA_TRACE
@@ -229,7 +339,7 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
   typedef DmaStager<T, D, 64, 4> DS;
   constexpr int BN = 64, RW = 64, NW = 4, BM = RW * NW;
   constexpr int TILE_B = BN * G::ROWB;             // 16 KiB
-  static_assert(TILE_B == 16384 && DS::PER == 4 && DS::UNIFORM, "fwd3 geometry");
+  static_assert(TILE_B == 16384 && DS::PER == 4 && DS::UNIFORM && R >= 3, "fwd3 geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [R] K tiles | [R] V tiles; the epilogue scratch reuses the bytes
 
   const int tid = threadIdx.x;
@@ -257,6 +367,11 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
   ts.reset();
 #ifdef FCSA_TRACE
   const unsigned long long trace_t0 = trace_now();
+  unsigned long long pm[2][8];
+  for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 8; ++b_) pm[a_][b_] = 0;
+#define FCSA_PASS_MARK(k) pm[pass][k] = trace_now()
+#else
+#define FCSA_PASS_MARK(k) ((void)0)
 #endif
   F3State<T> st;
   {
@@ -281,26 +396,56 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
     if (p.causal) last_key = min(last_key, m0 + BM - 1 + diff);
     const int nt = last_key < 0 ? 0 : last_key / BN + 1;
 
-    // ---- prologue: the ring's first tiles by LDS-DMA (K(0..R-1); V(-1) = zeros in slot R-1; V(0..R-2)), then the query rows ----
+    FCSA_PASS_MARK(0);
+    // ---- prologue: the query rows, then the ring's first tiles by LDS-DMA (K(0..R-2); V(-1) = zeros in slot R-1; V(0..R-3)) ----
+    u32x4 qf[2][8];
+    {
+      const char* qbase = p.q.p + (int64_t)b * p.q.sb + (int64_t)h * p.q.sh;
+      int64_t qbytes = (int64_t)(p.N - 1) * p.q.sn + D * 2;
+      if (qbytes > 0x7fffffff) qbytes = 0x7fffffff;
+      const uint64_t qa = reinterpret_cast<uint64_t>(qbase);
+      u32x4 qrs;
+      qrs[0] = __builtin_amdgcn_readfirstlane((uint32_t)qa);
+      qrs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32) & 0xffffu);
+      qrs[2] = __builtin_amdgcn_readfirstlane((uint32_t)qbytes);
+      qrs[3] = 0x00020000u;
+      const int hio = opaque(fa.hi);
+      const uint32_t qv0 = (uint32_t)i0 * (uint32_t)p.q.sn + (uint32_t)hio * 16u, qv1 = qv0 + 32u * (uint32_t)p.q.sn;      // (launcher: N * pitch < 2 GiB)
+      static_for<8>([&](auto kc) { constexpr int kk = decltype(kc)::value; q_load<32 * kk, kk == 0>(qf[0][kk], qv0, qrs); });
+      static_for<8>([&](auto kc) { constexpr int kk = decltype(kc)::value; q_load<32 * kk, false>(qf[1][kk], qv1, qrs); });
+    }
+    // The 4 (2R - 2) DMA pieces of the ring's first tiles are expensive to ISSUE back to back at a cold start (the trace: 6.7 k ticks for
+    // the 24 of R = 4, the vector-memory queue is full), so only the tiles the first period needs -- V(-1) = zeros, K(0), V(0) -- go out
+    // ahead of the counted wait; the others are issued between the two rows' l2norm arithmetic, which their flight then covers.
     typename DS::Stream stk = dk_.open(kbase, p.k.sn, p.M), stv = dv_.open(vbase, p.v.sn, p.M);
     {
       const typename DS::Stream stz = dv_.open(vbase, p.v.sn, 0);      // zero records: the DMA writes zeros
       dv_.issue(stz, lds0 + (2 * R - 1) * TILE_B, wave);
+      dk_.issue(stk, lds0, wave);
+      stk.off += k_step;
+      dv_.issue(stv, lds0 + R * TILE_B, wave);
+      stv.off += v_step;
+    }
+    FCSA_PASS_MARK(1);
+    u32x4 krs, vrs;      // the streams' descriptors, provably in SGPRs for the loop's DMA statements
 #pragma unroll
-      for (int s = 0; s < R; ++s) {
+    for (int e = 0; e < 4; ++e) { krs[e] = __builtin_amdgcn_readfirstlane(stk.rs[e]); vrs[e] = __builtin_amdgcn_readfirstlane(stv.rs[e]); }
+    q_wait<12>(qf);      // the rows have landed; the 12 DMA pieces behind them stay in flight
+    {
+      const int hio = opaque(fa.hi);
+      fwd3_finish_q<T>(p, b, h, i0, hio, qf[0]);
+#pragma unroll
+      for (int s = 1; s < R - 1; ++s) {      // K(1..R-2), V(1..R-3)
         dk_.issue(stk, lds0 + s * TILE_B, wave);
         stk.off += k_step;
-        if (s < R - 1) {
+        if (s < R - 2) {
           dv_.issue(stv, lds0 + (R + s) * TILE_B, wave);
           stv.off += v_step;
         }
       }
+      fwd3_finish_q<T>(p, b, h, i0 + 32, hio, qf[1]);
     }
-    u32x4 qf[2][8];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) request_q_rows<T, D>(p, b, h, i0 + 32 * r, fa.hi, qf[r]);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) finish_q_frags<T, D, true>(p, b, h, i0 + 32 * r, fa, qf[r]);
+    FCSA_PASS_MARK(2);
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -318,7 +463,7 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st.s[1][r][e] = -1e30f;
+      for (int e = 0; e < 16; ++e) st.s[1][r][e] = r == 0 ? 0.f : -1e30f;      // rows 0..31: "already exponentiated" (only its tail is pending)
       const u32x4 z4 = {0u, 0u, 0u, 0u};
       st.pk[1][r][0] = z4;
       st.pk[1][r][1] = z4;
@@ -332,8 +477,10 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
 #pragma unroll
       for (int half = 0; half < 2; ++half)                                                                                   // V slot R - 1
         st.va[2 * db + half] = lds0 + (2 * R - 1) * TILE_B + fa.tr_off[half] + (((4 * db + fa.tr_col) ^ fa.tr_swz[half]) << 4);
+    FCSA_PASS_MARK(3);
     wait_vm<0>();
     wg_barrier();
+    FCSA_PASS_MARK(4);
     static_for<8>([&](auto kc) { lds_read_k<0>(st.kf[decltype(kc)::value], st.ka[decltype(kc)::value]); });      // K(0), key block 0
 
     // thresholds: key j of the tile at j0 is visible to this lane's row i iff  j <= min(i + diff, M - 1); the lane compares the
@@ -350,10 +497,11 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
     auto run = [&](auto masked_tag, int t_begin, int t_end) {
       constexpr bool MASKED = decltype(masked_tag)::value;
       for (int t = t_begin; t < t_end; ++t) {
-        const uint32_t lds_k = lds0 + (uint32_t)slot * TILE_B;                                   // K(t+R)   -> slot of K(t)
-        const uint32_t lds_v = lds0 + (uint32_t)(R + (slot == 0 ? R - 1 : slot - 1)) * TILE_B;   // V(t+R-1) -> slot of V(t-1)
-        auto dma_k = [&](int i) { dk_.issue_piece(stk, lds_k, i, wave); };
-        auto dma_v = [&](int i) { dv_.issue_piece(stv, lds_v, i, wave); };
+        const int sm1 = slot == 0 ? R - 1 : slot - 1, sm2 = sm1 == 0 ? R - 1 : sm1 - 1;
+        const uint32_t lds_k = lds0 + (uint32_t)sm1 * TILE_B + (uint32_t)wave * 1024u;               // K(t+R-1) -> slot of K(t-1)
+        const uint32_t lds_v = lds0 + (uint32_t)(R + sm2) * TILE_B + (uint32_t)wave * 1024u;         // V(t+R-2) -> slot of V(t-2)
+        auto dma_k = [&](int i) { dma_piece(lds_k + (uint32_t)i * 4096u, (uint32_t)dk_.piece_offset(i), krs, stk.off); };
+        auto dma_v = [&](int i) { dma_piece(lds_v + (uint32_t)i * 4096u, (uint32_t)dv_.piece_offset(i), vrs, stv.off); };
         const uint32_t dk_next = slot + 1 == R ? (uint32_t)(-(R - 1) * TILE_B) : (uint32_t)TILE_B;      // slot(t) -> slot(t+1)
         const uint32_t dv_next = slot == 0 ? (uint32_t)(-(R - 1) * TILE_B) : (uint32_t)TILE_B;          // slot(t-1) -> slot(t)
         const int j0 = t * BN;
@@ -367,7 +515,9 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
       }
     };
     run(std::false_type{}, 0, t_split);
+    FCSA_PASS_MARK(5);
     run(std::true_type{}, t_split, nt);
+    FCSA_PASS_MARK(6);
     if (nt > 0) {
       const int jl = (nt - 1) * BN;
       const int thr_last[2] = {thr0[0] - jl, thr0[1] - jl};
@@ -390,13 +540,17 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
         RowEpilogue<T, D>::store(scr, st.o[r], inv, lane, out0, p.o.sn, rows_valid, false, nullptr, 0, 1.f, nullptr, 1, 0, 1.f);
       }
     }
+    FCSA_PASS_MARK(7);
     if (pass + 1 < npass) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       wg_barrier();              // the scratch is free again before the next pass's DMA overwrites it
     }
   }   // pass
 #ifdef FCSA_TRACE
-  if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) ts.dump(g_trace_fwd3 + 32 * wave, trace_now() - trace_t0);
+  if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) {
+    ts.dump(g_trace_fwd3 + 32 * wave, trace_now() - trace_t0);
+    for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 8; ++b_) g_trace_fwd3[32 * wave + 14 + 8 * a_ + b_] = pm[a_][b_] ? pm[a_][b_] - trace_t0 : 0;
+  }
 #endif
 }
 #ifdef FCSA_TRACE
@@ -407,7 +561,7 @@ extern "C" int fcsa_trace_read_fwd3(unsigned long long* out) {
 namespace fcsa {
 #endif
 
-constexpr int kFwd3Ring = 3;             // K and V ring depth (tiles): 96 KiB of the CU's 160
+constexpr int kFwd3Ring = 4;             // K and V ring depth (tiles): 128 KiB of the CU's 160; K is requested 3 tiles ahead, V 2
 constexpr bool kFwd3RoundedSums = false; // row sums of the un-rounded P~ (two adds) or of the rounded pair (v_dot2c)
 
 template <typename T, int R, bool RSUM, int ABL = 0>
@@ -433,6 +587,7 @@ bool use_forward_wide128(int dtype, int D, const FwdParams& p) {
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
   if (wgs < cu_count() * 7 / 8) return false;
   if ((int64_t)(p.M + 64 * 6) * p.k.sn >= 0x7fffffffLL || (int64_t)(p.M + 64 * 6) * p.v.sn >= 0x7fffffffLL) return false;
+  if ((int64_t)(p.N + 256) * p.q.sn >= 0x7fffffffLL) return false;
   return true;
 }
 
@@ -441,15 +596,14 @@ static hipError_t launch_fwd3_v(const FwdParams& p, hipStream_t s) {
 #ifdef FCSA_FWD3_AB      // development builds only (tools/build_dev.sh): ring depth / row-sum form chosen per launch, FCSA_FWD_WIDE128=r<depth>[d]
   if (const char* e = std::getenv("FCSA_FWD_WIDE128"); e != nullptr && e[0] == 'r') {
     const bool d = e[2] == 'd';
-    if (e[1] == '2') return d ? launch_fwd3_t<T, 2, true>(p, s) : launch_fwd3_t<T, 2, false>(p, s);
     if (e[1] == '3') return d ? launch_fwd3_t<T, 3, true>(p, s) : launch_fwd3_t<T, 3, false>(p, s);
     if (e[1] == '4') return d ? launch_fwd3_t<T, 4, true>(p, s) : launch_fwd3_t<T, 4, false>(p, s);
-    if (e[1] == 'x') return launch_fwd3_t<T, 3, false, 1>(p, s);       // ablations (wrong results, timing only): exp -> mul
-    if (e[1] == 'y') return launch_fwd3_t<T, 3, false, 2>(p, s);       //   no DMA in the loop
-    if (e[1] == 'z') return launch_fwd3_t<T, 3, false, 4>(p, s);       //   no waits / barrier between P2 and P3
-    if (e[1] == 'w') return launch_fwd3_t<T, 3, false, 8>(p, s);       //   no softmax VALU work
-    if (e[1] == 'v') return launch_fwd3_t<T, 3, false, 16>(p, s);      //   no LDS reads
-    if (e[1] == 'u') return launch_fwd3_t<T, 3, false, 30>(p, s);      //   MFMAs only
+    if (e[1] == 'x') return launch_fwd3_t<T, 4, false, 1>(p, s);       // ablations (wrong results, timing only): exp -> mul
+    if (e[1] == 'y') return launch_fwd3_t<T, 4, false, 2>(p, s);       //   no DMA in the loop
+    if (e[1] == 'z') return launch_fwd3_t<T, 4, false, 4>(p, s);       //   no waits / barrier between P2 and P3
+    if (e[1] == 'w') return launch_fwd3_t<T, 4, false, 8>(p, s);       //   no softmax VALU work
+    if (e[1] == 'v') return launch_fwd3_t<T, 4, false, 16>(p, s);      //   no LDS reads
+    if (e[1] == 'u') return launch_fwd3_t<T, 4, false, 30>(p, s);      //   MFMAs only
   }
 #endif
   return launch_fwd3_t<T, kFwd3Ring, kFwd3RoundedSums>(p, s);

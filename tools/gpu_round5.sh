@@ -20,12 +20,15 @@ for step in "$@"; do
       tail -n 40 gpurun_out/pytest_wide.log | cut -c1-400 ;;
     ab)
       if [ -n "${FCSA_CANARY_FAILED:-}" ]; then echo "skipped (canary)"; continue; fi
-      timeout 600 python tools/fwd3_ab.py --variants 0 r2 r3 r4 r3d r2d > gpurun_out/fwd3_ab.txt 2>&1; cat gpurun_out/fwd3_ab.txt
-      timeout 300 python tools/fwd3_ab.py --dtype f16 --shapes 4,8,4096,4096,1 --variants 0 r3 r3d > gpurun_out/fwd3_ab_f16.txt 2>&1; cat gpurun_out/fwd3_ab_f16.txt ;;
+      timeout 600 python tools/fwd3_ab.py --variants ${AB_VARIANTS:-0 r3 r4 r4d} > gpurun_out/fwd3_ab.txt 2>&1; cat gpurun_out/fwd3_ab.txt
+      ;;
     abl)      # ablations of the wide form's tile loop (development build of the library: wrong results, timing only) + phase trace
-      timeout 600 python tools/fwd3_ab.py --shapes 4,8,4096,4096,0 4,8,4096,4096,1 --variants 0 r3 rx ry rz rw rv ru --rounds 3 > gpurun_out/fwd3_abl.txt 2>&1; cat gpurun_out/fwd3_abl.txt
+      timeout 600 python tools/fwd3_ab.py --shapes 4,8,4096,4096,0 4,8,4096,4096,1 --variants ${ABL_VARIANTS:-0 r4 rx ry rz rw rv ru} --rounds 3 > gpurun_out/fwd3_abl.txt 2>&1; cat gpurun_out/fwd3_abl.txt
       FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 0 > gpurun_out/trace_fwd3.txt 2>&1
       FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 1 >> gpurun_out/trace_fwd3.txt 2>&1; cat gpurun_out/trace_fwd3.txt ;;
+    trace)
+      FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 0 > gpurun_out/trace_fwd3.txt 2>&1
+      FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 1 >> gpurun_out/trace_fwd3.txt 2>&1; grep -v amdgpu.ids gpurun_out/trace_fwd3.txt | grep 'pass\|wave' ;;
     suite)    # the whole GPU suite as shipped
       rm -f gpurun_out/tol_log.jsonl
       FCSA_TOL_LOG=$PWD/gpurun_out/tol_log.jsonl timeout 1800 python -m pytest tests -m gpu -q --maxfail=200 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1

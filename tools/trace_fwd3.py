@@ -32,3 +32,9 @@ for w in range(4):
     print(f"wave {w}: unmasked tiles {it}, counted {sum(seg)} of kernel total {total} ticks ({100.0 * sum(seg) / max(total, 1):.1f}%), per tile {sum(seg) / it:.0f} ticks")
     for n, s_ in zip(names, seg):
         print(f"    {n:<62} {s_ / it:8.1f} ticks/tile  {100.0 * s_ / max(sum(seg), 1):5.1f}%")
+    marks = ["pass start", "DMA of the first tiles issued", "q rows loaded + l2norm + published", "q -> accumulator file, state init", "vmcnt(0) + barrier: first tiles visible",
+             "unmasked tiles done", "masked tiles done", "drain + epilogue done"]
+    for ps in range(2):
+        m = a[14 + 8 * ps:22 + 8 * ps]
+        if m[7] == 0: continue
+        print(f"    pass {ps}: " + " | ".join(f"{marks[i]} +{m[i] - (m[i - 1] if i else (a[14 + 8 * (ps - 1) + 7] if ps else 0)):d}" for i in range(8)))
