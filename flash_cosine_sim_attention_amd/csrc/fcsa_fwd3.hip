@@ -27,10 +27,17 @@
 //     P3  S1(t)    | softmax of (t, kb 0, rows 32..63)   | V^T reads of (t, kb 0)
 //     P4  PV0(t)   | softmax of (t, kb 1, rows 0..31)    | K reads of (t+1, kb 0)   | LDS-DMA V(t+R-2) -> slot of V(t-2)
 //
-// i.e. <= 5 fillers per MFMA gap (one exp, one add, a cvt_pk every other gap, <= 2 LDS reads or an address step / DMA piece), one barrier per tile, rings of
-// R tiles for K and for V.  Row sums are plain f32 adds of the un-rounded P~ (four partial sums per row pair: v_dot2c on the packed
-// values costs more than two adds beside MFMAs, MI355X guide "price of one filler").  Tiles that need masking for a wave (the causal
-// diagonal, a ragged last tile) run a second instantiation of the same body with a compare + select in front of each exp.
+// i.e. <= 5 fillers per MFMA gap (one exp, one add, a cvt_pk every other gap, <= 2 LDS reads or an address step / DMA piece), one barrier
+// per tile, rings of R tiles for K and for V.  Row sums are plain f32 adds of the un-rounded P~ (two partial sums per row block: v_dot2c
+// on the packed values costs more than two adds beside MFMAs, MI355X guide "price of one filler"; measured +5 ... 7 %).  Tiles that
+// need masking for a wave (the causal diagonal, a ragged last tile) run a second instantiation of the same body with a compare + select
+// in front of each exp.
+//
+// Measured (MI355X, bf16, forward call = k-l2norm launch + this kernel; same-process A/B against the lean 32-row form, profiles/r05_fwd3_*):
+// (4,8,4096,128) causal 149 -> 138 us, non-causal 256 -> 231, (16,8,2048,128) causal 191 -> 181, (2,8,8192,128) causal 258 -> 235.
+// Phase trace: 2480 ticks per 64-MFMA tile (matrix floor 2048): S phases 615 - 635, PV phases 578, barrier 60 - 100; per pass
+// ~12 k ticks of prologue (rows + fused l2norm under the first tiles' flight) and ~7 k of drain + epilogue.  Version history of the
+// schedule with its traces: profiles/NOTES.md (round 5).
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -93,12 +100,11 @@ template <typename T> struct F3State {
 //     gap G:  (select,) exp of register G  |  row-sum add of register G - 1  |  even G >= 2: pack of registers G - 2, G - 1
 // so every consumer sits one MFMA behind its producer, and the tail -- the add of register 15 and the pack of registers 14, 15 -- is the
 // head of the NEXT phase's gap 0 (`sm_tail`), whatever block half that phase works on.
-template <bool MASKED, int R_, int KOFF, int ABL> FCSA_DEV void sm_exp1(f32x16& s, int thr, float ninf) {
+template <bool MASKED, int R_, int KOFF> FCSA_DEV void sm_exp1(f32x16& s, int thr, float ninf) {
   if constexpr (MASKED) {      // key row KOFF + crow(r, 0) (relative to this lane's threshold, which carries j0 and 4 * hi) is visible iff <= thr
     asm volatile("v_cmp_le_i32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc" : "+v"(s[R_]) : "v"(thr), "n"(KOFF + crow(R_, 0)), "v"(ninf) : "vcc");
   }
-  if constexpr ((ABL & 1) != 0) asm volatile("v_mul_f32_e32 %0, %0, %0" : "+v"(s[R_]));      // (ablation: a plain VALU instruction)
-  else asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[R_]));
+  asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[R_]));
 }
 // RSUM: the row sum takes the ROUNDED pair (v_dot2c against packed ones, like the other 16-bit forward forms: O is then a true convex
 // combination of V rows); else the un-rounded values (plain adds, two partial sums per row block)
@@ -111,17 +117,15 @@ template <typename T, bool RSUM, int E> FCSA_DEV void sm_pack1(const f32x16& s, 
   if constexpr (RSUM) Ins<T>::add_pair(l[E & 1], u, one2);
   pk[E >> 2][E & 3] = u;
 }
-template <typename T, bool RSUM, bool MASKED, int HALF, int G, int KOFF, int ABL = 0>
+template <typename T, bool RSUM, bool MASKED, int HALF, int G, int KOFF>
 FCSA_DEV void sm_gap(F3State<T>& st, f32x16 (&s)[2], u32x4 (&pk)[2][2], const int (&thr)[2]) {
-  if constexpr ((ABL & 8) != 0) return;      // (ablation: no softmax work at all)
   if constexpr (G >= 1) sm_add1<RSUM, G - 1>(s[HALF], st.l[HALF]);
-  sm_exp1<MASKED, G, KOFF, ABL>(s[HALF], thr[HALF], st.ninf);
+  sm_exp1<MASKED, G, KOFF>(s[HALF], thr[HALF], st.ninf);
   if constexpr (G >= 2 && (G & 1) == 0) sm_pack1<T, RSUM, (G - 2) / 2>(s[HALF], pk[HALF], st.l[HALF], st.one2);
 }
 // the tail of the block half the PREVIOUS phase worked on
-template <typename T, bool RSUM, int HALF, int ABL = 0>
+template <typename T, bool RSUM, int HALF>
 FCSA_DEV void sm_tail(F3State<T>& st, f32x16 (&s)[2], u32x4 (&pk)[2][2]) {
-  if constexpr ((ABL & 8) != 0) return;
   sm_add1<RSUM, 15>(s[HALF], st.l[HALF]);
   sm_pack1<T, RSUM, 7>(s[HALF], pk[HALF], st.l[HALF], st.one2);
 }
@@ -145,18 +149,18 @@ FCSA_DEV void addr_step(uint32_t& a, uint32_t delta) { asm volatile("v_add_u32_e
 // S phase of key block KB: 16 MFMAs (k-step outer, row block inner: the two chains alternate), the K fragments of this block were
 // requested during the previous phase.  `filler(g)` = this gap's softmax share; V^T fragments at va + VOFF (key block, 16-key step) are
 // requested two reads per gap in gaps 0..7; `extra(g)` = address steps / DMA pieces of this phase.
-template <typename T, int VOFF, int ABL, typename Filler, typename Extra>
+template <typename T, int VOFF, typename Filler, typename Extra>
 FCSA_DEV void s_phase(F3State<T>& st, f32x16 (&sblk)[2], Filler&& filler, Extra&& extra) {
   static_for<16>([&](auto gc) {
     constexpr int g = decltype(gc)::value, ks = g >> 1, qb = g & 1;
     // K fragment ks has landed: behind it are 7 - ks K reads and the V^T reads this phase has issued so far (LDS reads return in order)
-    if constexpr (qb == 0 && (ABL & 16) == 0) wait_lgkm<cmin<15, (7 - ks) + 2 * cmin<g, 8>()>()>();
+    if constexpr (qb == 0) wait_lgkm<cmin<15, (7 - ks) + 2 * cmin<g, 8>()>()>();
     if constexpr (ks == 0) Ins<T>::s_first(sblk[qb], st.kf[0], st.q[qb][0], st.cinit);
     else Ins<T>::s_next(sblk[qb], st.kf[ks], st.q[qb][ks]);
     filler(gc);
     // V^T fragment f = g in the first eight gaps, both halves: (16-key step f / 4, feature block f % 4) -- consumed in that order by the PV
     // phase.  (One read per gap over all sixteen gaps measured +90 ticks per S phase: profiles/r05_fwd3_trace_v4.txt.)
-    if constexpr (g < 8 && (ABL & 16) == 0) {
+    if constexpr (g < 8) {
       lds_read_vt_half<VOFF + 16 * (g >> 2) * 256, 0>(st.vfh[g], st.va[2 * (g & 3)]);
       lds_read_vt_half<VOFF + 16 * (g >> 2) * 256, 1>(st.vfh[g], st.va[2 * (g & 3) + 1]);
     }
@@ -165,15 +169,15 @@ FCSA_DEV void s_phase(F3State<T>& st, f32x16 (&sblk)[2], Filler&& filler, Extra&
 }
 // PV phase of a key block: 16 MFMAs (16-key step outer, feature block, row block inner: a fragment feeds two MFMAs, an accumulator
 // returns after 8).  K fragments at ka + KOFFB are requested one per gap in gaps 0..7.
-template <typename T, int KOFFB, int ABL, typename Filler, typename Extra>
+template <typename T, int KOFFB, typename Filler, typename Extra>
 FCSA_DEV void pv_phase(F3State<T>& st, u32x4 (&pblk)[2][2], Filler&& filler, Extra&& extra) {
   static_for<16>([&](auto gc) {
     constexpr int g = decltype(gc)::value, f = g >> 1, qb = g & 1, ks2 = f >> 2, db = f & 3;
     // V^T fragment f (reads 2f, 2f + 1 of 16) has landed: behind it are 14 - 2f V^T reads and the K reads issued so far
-    if constexpr (qb == 0 && (ABL & 16) == 0) wait_lgkm<cmin<15, (14 - 2 * f) + cmin<g, 8>()>()>();
+    if constexpr (qb == 0) wait_lgkm<cmin<15, (14 - 2 * f) + cmin<g, 8>()>()>();
     Ins<T>::pv(st.o[qb][db], vt_frag(st.vfh[f]), pblk[qb][ks2]);
     filler(gc);
-    if constexpr (g < 8 && (ABL & 16) == 0) lds_read_k<KOFFB>(st.kf[g], st.ka[g]);
+    if constexpr (g < 8) lds_read_k<KOFFB>(st.kf[g], st.ka[g]);
     extra(gc);
   });
 }
@@ -182,53 +186,51 @@ FCSA_DEV void pv_phase(F3State<T>& st, u32x4 (&pblk)[2][2], Filler&& filler, Ext
 // thr_prev / thr_cur: per-lane visibility thresholds of the tile whose block 1 is still in flight and of this tile (MASKED only).
 // The LDS-DMA pieces ride in the PV phases (a piece costs ~45 ticks there, ~90 beside the 16 transposed reads of an S phase): K(t+R-1)
 // into the slot of K(t-1) during P2, V(t+R-2) into the slot of V(t-2) during P4 -- both slots were released by the PREVIOUS tile's barrier.
-template <typename T, int R, bool RSUM, bool MASKED, int ABL, typename DmaK, typename DmaV>
+template <typename T, int R, bool RSUM, bool MASKED, typename DmaK, typename DmaV>
 FCSA_DEV void fwd3_tile(F3State<T>& st, Trace& ts, uint32_t dk_next, uint32_t dv_next, const int (&thr_prev)[2], const int (&thr_cur)[2], DmaK&& dma_k, DmaV&& dma_v) {
   // P1: S0(t) | softmax of (t-1, kb 1, rows 32..63) [tail of (t-1, kb 1, rows 0..31)] | V^T reads of (t-1, kb 1) | va: V(t-1) -> V(t)
   FCSA_STAMP(ts, 0);
-  s_phase<T, 8192, ABL>(st, st.s[0],
+  s_phase<T, 8192>(st, st.s[0],
                         [&](auto gc) {
                           constexpr int g = decltype(gc)::value;
-                          if constexpr (g == 0) sm_tail<T, RSUM, 0, ABL>(st, st.s[1], st.pk[1]);
-                          sm_gap<T, RSUM, MASKED, 1, g, 32, ABL>(st, st.s[1], st.pk[1], thr_prev);
+                          if constexpr (g == 0) sm_tail<T, RSUM, 0>(st, st.s[1], st.pk[1]);
+                          sm_gap<T, RSUM, MASKED, 1, g, 32>(st, st.s[1], st.pk[1], thr_prev);
                         },
                         [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8) addr_step(st.va[g - 8], dv_next); });
   FCSA_STAMP(ts, 1);
   // P2: PV1(t-1) | softmax of (t, kb 0, rows 0..31) [tail of (t-1, kb 1, rows 32..63)] | K reads of (t, kb 1) | DMA K(t+R-1)
-  pv_phase<T, 8192, ABL>(st, st.pk[1],
+  pv_phase<T, 8192>(st, st.pk[1],
                          [&](auto gc) {
                            constexpr int g = decltype(gc)::value;
-                           if constexpr (g == 0) sm_tail<T, RSUM, 1, ABL>(st, st.s[1], st.pk[1]);
-                           sm_gap<T, RSUM, MASKED, 0, g, 0, ABL>(st, st.s[0], st.pk[0], thr_cur);
+                           if constexpr (g == 0) sm_tail<T, RSUM, 1>(st, st.s[1], st.pk[1]);
+                           sm_gap<T, RSUM, MASKED, 0, g, 0>(st, st.s[0], st.pk[0], thr_cur);
                          },
-                         [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_k((g - 8) >> 1); });
+                         [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0) dma_k((g - 8) >> 1); });
   FCSA_STAMP(ts, 2);
   // every wave is done with K(t) and V(t-1) -- lgkmcnt(0): its reads of them have RETURNED (the K reads went out >= 8 gaps ago: free),
   // so a DMA behind the barrier cannot overtake a read; the pieces of K(t+1) and V(t) that THIS wave requested have landed (vmcnt: the
   // 8 pieces of every younger period and the 4 of this P2 may stay in flight), the barrier publishes all
-  if constexpr ((ABL & 4) == 0) {
-    wait_lgkm<0>();
-    wait_vm<8 * (R - 3) + 4>();
-    wg_barrier();
-  }
+  wait_lgkm<0>();
+  wait_vm<8 * (R - 3) + 4>();
+  wg_barrier();
   FCSA_STAMP(ts, 3);
   // P3: S1(t) | softmax of (t, kb 0, rows 32..63) [tail of (t, kb 0, rows 0..31)] | V^T reads of (t, kb 0) | ka: K(t) -> K(t+1)
-  s_phase<T, 0, ABL>(st, st.s[1],
+  s_phase<T, 0>(st, st.s[1],
                      [&](auto gc) {
                        constexpr int g = decltype(gc)::value;
-                       if constexpr (g == 0) sm_tail<T, RSUM, 0, ABL>(st, st.s[0], st.pk[0]);
-                       sm_gap<T, RSUM, MASKED, 1, g, 0, ABL>(st, st.s[0], st.pk[0], thr_cur);
+                       if constexpr (g == 0) sm_tail<T, RSUM, 0>(st, st.s[0], st.pk[0]);
+                       sm_gap<T, RSUM, MASKED, 1, g, 0>(st, st.s[0], st.pk[0], thr_cur);
                      },
                      [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8) addr_step(st.ka[g - 8], dk_next); });
   FCSA_STAMP(ts, 4);
   // P4: PV0(t) | softmax of (t, kb 1, rows 0..31) [tail of (t, kb 0, rows 32..63)] | K reads of (t+1, kb 0) | DMA V(t+R-2)
-  pv_phase<T, 0, ABL>(st, st.pk[0],
+  pv_phase<T, 0>(st, st.pk[0],
                       [&](auto gc) {
                         constexpr int g = decltype(gc)::value;
-                        if constexpr (g == 0) sm_tail<T, RSUM, 1, ABL>(st, st.s[0], st.pk[0]);
-                        sm_gap<T, RSUM, MASKED, 0, g, 32, ABL>(st, st.s[1], st.pk[1], thr_cur);
+                        if constexpr (g == 0) sm_tail<T, RSUM, 1>(st, st.s[0], st.pk[0]);
+                        sm_gap<T, RSUM, MASKED, 0, g, 32>(st, st.s[1], st.pk[1], thr_cur);
                       },
-                      [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0 && (ABL & 2) == 0) dma_v((g - 8) >> 1); });
+                      [&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (g >= 8 && (g & 1) == 0) dma_v((g - 8) >> 1); });
   FCSA_STAMP(ts, 5);
 }
 
@@ -332,7 +334,7 @@ FCSA_DEV void fwd3_finish_q(const FwdParams& p, int b, int h, int i, int hi_, u3
 __device__ unsigned long long g_trace_fwd3[128];
 #endif
 
-template <typename T, int R, bool RSUM, int ABL = 0>
+template <typename T, int R, bool RSUM>
 __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
   constexpr int D = 128;
   typedef TileGeom<D, 2> G;
@@ -507,7 +509,7 @@ __global__ void __launch_bounds__(256, 1) fwd3_kernel(const FwdParams p) {
         const int j0 = t * BN;
         const int thr_cur[2] = {thr0[0] - j0, thr0[1] - j0};
         const int thr_prev[2] = {thr_cur[0] + BN, thr_cur[1] + BN};
-        fwd3_tile<T, R, RSUM, MASKED, ABL>(st, ts, dk_next, dv_next, thr_prev, thr_cur, dma_k, dma_v);
+        fwd3_tile<T, R, RSUM, MASKED>(st, ts, dk_next, dv_next, thr_prev, thr_cur, dma_k, dma_v);
         if constexpr (!MASKED) ts.close(5);
         stk.off += k_step;
         stv.off += v_step;
@@ -562,15 +564,16 @@ namespace fcsa {
 #endif
 
 constexpr int kFwd3Ring = 4;             // K and V ring depth (tiles): 128 KiB of the CU's 160; K is requested 3 tiles ahead, V 2
-constexpr bool kFwd3RoundedSums = false; // row sums of the un-rounded P~ (two adds) or of the rounded pair (v_dot2c)
+constexpr bool kFwd3RoundedSums = false; // row sums of the un-rounded P~ (plain adds); true = of the rounded pair (v_dot2c: bit-identical to the
+                                         // lean form's output, +5 ... 7 % time: profiles/r05_fwd3_ab_v2.txt)
 
-template <typename T, int R, bool RSUM, int ABL = 0>
+template <typename T, int R, bool RSUM>
 static hipError_t launch_fwd3_t(const FwdParams& p, hipStream_t s) {
   const int MT = (p.N + 255) / 256;
   const int PT = p.causal ? (MT + 1) / 2 : MT;
   size_t lds = (size_t)2 * R * 16384;
   if (lds < (size_t)4 * RowEpilogue<T, 128>::BYTES_NOX) lds = (size_t)4 * RowEpilogue<T, 128>::BYTES_NOX;
-  auto kern = fwd3_kernel<T, R, RSUM, ABL>;
+  auto kern = fwd3_kernel<T, R, RSUM>;
   static std::atomic<uint64_t> lds_ok{0};
   if (hipError_t e = ensure_dynamic_lds(kern, lds, lds_ok); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H * PT)), dim3(256), lds, s, p);
@@ -591,26 +594,8 @@ bool use_forward_wide128(int dtype, int D, const FwdParams& p) {
   return true;
 }
 
-template <typename T>
-static hipError_t launch_fwd3_v(const FwdParams& p, hipStream_t s) {
-#ifdef FCSA_FWD3_AB      // development builds only (tools/build_dev.sh): ring depth / row-sum form chosen per launch, FCSA_FWD_WIDE128=r<depth>[d]
-  if (const char* e = std::getenv("FCSA_FWD_WIDE128"); e != nullptr && e[0] == 'r') {
-    const bool d = e[2] == 'd';
-    if (e[1] == '3') return d ? launch_fwd3_t<T, 3, true>(p, s) : launch_fwd3_t<T, 3, false>(p, s);
-    if (e[1] == '4') return d ? launch_fwd3_t<T, 4, true>(p, s) : launch_fwd3_t<T, 4, false>(p, s);
-    if (e[1] == 'x') return launch_fwd3_t<T, 4, false, 1>(p, s);       // ablations (wrong results, timing only): exp -> mul
-    if (e[1] == 'y') return launch_fwd3_t<T, 4, false, 2>(p, s);       //   no DMA in the loop
-    if (e[1] == 'z') return launch_fwd3_t<T, 4, false, 4>(p, s);       //   no waits / barrier between P2 and P3
-    if (e[1] == 'w') return launch_fwd3_t<T, 4, false, 8>(p, s);       //   no softmax VALU work
-    if (e[1] == 'v') return launch_fwd3_t<T, 4, false, 16>(p, s);      //   no LDS reads
-    if (e[1] == 'u') return launch_fwd3_t<T, 4, false, 30>(p, s);      //   MFMAs only
-  }
-#endif
-  return launch_fwd3_t<T, kFwd3Ring, kFwd3RoundedSums>(p, s);
-}
-
 hipError_t launch_forward_wide128(int dtype, const FwdParams& p, hipStream_t s) {
-  return dtype == 2 ? launch_fwd3_v<BF16>(p, s) : launch_fwd3_v<F16>(p, s);
+  return dtype == 2 ? launch_fwd3_t<BF16, kFwd3Ring, kFwd3RoundedSums>(p, s) : launch_fwd3_t<F16, kFwd3Ring, kFwd3RoundedSums>(p, s);
 }
 
 }  // namespace fcsa

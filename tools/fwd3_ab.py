@@ -1,6 +1,7 @@
 """Interleaved same-process A/B of the D = 128 forward forms: FCSA_FWD_WIDE128 is read per launch (fcsa_fwd3.hip), so one process times
-the lean 32-row form ("0"), the product's wide form ("") and -- in a development build of the library (-DFCSA_FWD3_AB) -- ring depths
-and row-sum forms ("r2", "r3d", ...).  HIP-event timing of forward-only calls under no_grad, `rounds` interleaved rounds of `iters`.
+the lean 32-row form ("0") and the product's wide form ("").  (The development snapshots of round 5 -- commit "fcsa_fwd3 v2-v5" -- also
+understood ring depths, row-sum forms and ablations: "r3", "r4d", "rx" ...; the tables they produced are profiles/r05_fwd3_ab_v*.txt,
+r05_fwd3_ablations_v*.txt.)  HIP-event timing of forward-only calls under no_grad, `rounds` interleaved rounds of `iters`.
 usage: python tools/fwd3_ab.py [--shapes B,H,N,M,causal ...] [--variants 0 r3 ...] [--dtype bf16]"""
 import argparse
 import os
@@ -14,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", nargs="*", default=["4,8,4096,4096,1", "4,8,4096,4096,0", "16,8,2048,2048,1", "2,8,8192,8192,1"])
-    ap.add_argument("--variants", nargs="*", default=["0", ""])
+    ap.add_argument("--variants", nargs="*", default=["0", "on"])      # "on" = the product's dispatch (variable unset)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--iters", type=int, default=30)
@@ -37,7 +38,7 @@ def main():
         with torch.no_grad():
             for r in range(args.rounds + 1):
                 for vn in args.variants:
-                    if vn:
+                    if vn and vn != "on":
                         os.environ["FCSA_FWD_WIDE128"] = vn
                     else:
                         os.environ.pop("FCSA_FWD_WIDE128", None)
@@ -60,7 +61,7 @@ def main():
             med = ts[len(ts) // 2]
             d = (outs[vn].float() - base).abs().max().item()
             nan = int((~torch.isfinite(outs[vn])).sum().item())
-            print(f"   {vn or '(product)':10s} median {med:8.1f} us  min {ts[0]:8.1f}  {flops / med / 1e6:7.1f} TFLOP/s   max|o - o[{args.variants[0]}]| {d:.3e}  non-finite {nan}")
+            print(f"   {vn:10s} median {med:8.1f} us  min {ts[0]:8.1f}  {flops / med / 1e6:7.1f} TFLOP/s   max|o - o[{args.variants[0]}]| {d:.3e}  non-finite {nan}")
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ for step in "$@"; do
       tail -n 40 gpurun_out/pytest_wide.log | cut -c1-400 ;;
     ab)
       if [ -n "${FCSA_CANARY_FAILED:-}" ]; then echo "skipped (canary)"; continue; fi
-      timeout 600 python tools/fwd3_ab.py --variants ${AB_VARIANTS:-0 r3 r4 r4d} > gpurun_out/fwd3_ab.txt 2>&1; cat gpurun_out/fwd3_ab.txt
+      timeout 600 python tools/fwd3_ab.py --variants ${AB_VARIANTS:-0 on} > gpurun_out/fwd3_ab.txt 2>&1; cat gpurun_out/fwd3_ab.txt
       ;;
     abl)      # ablations of the wide form's tile loop (development build of the library: wrong results, timing only) + phase trace
       timeout 600 python tools/fwd3_ab.py --shapes 4,8,4096,4096,0 4,8,4096,4096,1 --variants ${ABL_VARIANTS:-0 r4 rx ry rz rw rv ru} --rounds 3 > gpurun_out/fwd3_abl.txt 2>&1; cat gpurun_out/fwd3_abl.txt
