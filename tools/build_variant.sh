@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../flash_cosine_sim_attention_amd/csrc"
 mkdir -p build_var
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form $FLAGS -c $TU.hip -o build_var/${TU}_$TAG.o
 OBJS=""
-for f in fcsa_fwd fcsa_bwd fcsa_norm fcsa_capi; do
+for f in fcsa_fwd fcsa_fwd3 fcsa_bwd fcsa_norm fcsa_capi; do
   if [ "$f" = "$TU" ]; then OBJS="$OBJS build_var/${TU}_$TAG.o"; else OBJS="$OBJS build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfcsa_hip_$TAG.so $OBJS

@@ -18,7 +18,7 @@ find gpurun_out/prof_stats -name "*kernel_trace.csv" -size +20M -delete
 echo "== dims sweep"; bash tools/dims_sweep.sh > gpurun_out/dims.log 2>&1; tail -n 44 gpurun_out/dims.txt | cut -c1-160
 echo "== benchmark.py --causal"; timeout 600 python benchmark.py --causal --dtypes bfloat16,float16 > gpurun_out/benchmark_causal.txt 2>&1; tail -n 18 gpurun_out/benchmark_causal.txt
 echo "== benchmark.py (non-causal, forward+backward)"; timeout 600 python benchmark.py --dtypes bfloat16,float16,float32 > gpurun_out/benchmark_full.txt 2>&1; tail -n 5 gpurun_out/benchmark_full.txt
-echo "== breakdown"; timeout 200 python tools/kernel_breakdown.py d64 d128 d96 C5 C5s8 C4 C2bias d64f32 f16s16 f16s16d128 C5s16 > gpurun_out/breakdown.txt 2>&1; tail -n 50 gpurun_out/breakdown.txt
+echo "== breakdown"; timeout 200 python tools/kernel_breakdown.py d64 d128 d96 C5 C5s8 C4 C2 C2bias d64f32 f16s16 f16s16d128 C5s16 > gpurun_out/breakdown.txt 2>&1; tail -n 50 gpurun_out/breakdown.txt
 echo "== forward: constant exponent shift vs online per-row reference"; timeout 200 python tools/fwd_dyn_ab.py > gpurun_out/fwd_dyn_ab.txt 2>&1; grep -v amdgpu.ids gpurun_out/fwd_dyn_ab.txt | tail -n 12
 echo "== host overhead"; for n in 128 512; do timeout 100 python tools/host_overhead.py $n > gpurun_out/host_$n.txt 2>&1; tail -n 13 gpurun_out/host_$n.txt; done
 echo "== per-workgroup pass timing (needs the FCSA_TRACE_WG build next to the library)"

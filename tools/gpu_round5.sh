@@ -31,7 +31,8 @@ for step in "$@"; do
       FCSA_LIB=$PWD/flash_cosine_sim_attention_amd/libfcsa_hip_trace.so timeout 300 python tools/trace_fwd3.py 1 >> gpurun_out/trace_fwd3.txt 2>&1; grep -v amdgpu.ids gpurun_out/trace_fwd3.txt | grep 'pass\|wave' ;;
     suite)    # the whole GPU suite as shipped
       rm -f gpurun_out/tol_log.jsonl
-      FCSA_TOL_LOG=$PWD/gpurun_out/tol_log.jsonl timeout 1800 python -m pytest tests -m gpu -q --maxfail=200 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      python -c "import os, torch; n = torch.cuda.device_count(); print('torch.cuda.device_count() =', n, [torch.cuda.get_device_name(i) for i in range(n)], 'HIP_VISIBLE_DEVICES =', os.environ.get('HIP_VISIBLE_DEVICES'), '(the two-device test of tests/test_gpu_misc.py runs only with >= 2)')" > gpurun_out/pytest_gpu.log 2>&1
+      FCSA_TOL_LOG=$PWD/gpurun_out/tol_log.jsonl timeout 1800 python -m pytest tests -m gpu -q --maxfail=200 -p no:cacheprovider >> gpurun_out/pytest_gpu.log 2>&1
       tail -n 15 gpurun_out/pytest_gpu.log | cut -c1-300 ;;
     bench)
       timeout 600 python bench.py > gpurun_out/bench.log 2>&1; tail -n 1 gpurun_out/bench.log > gpurun_out/bench_line.json; cut -c1-6000 gpurun_out/bench_line.json ;;
