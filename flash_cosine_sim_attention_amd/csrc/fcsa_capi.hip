@@ -283,7 +283,7 @@ int fcsa_debug(char* buf, size_t buf_bytes) {
   if (buf != nullptr && buf_bytes > 0) {
     snprintf(buf, buf_bytes,
              "libfcsa_hip abi=%d arch=gfx950 dtypes=f32,f16,bf16 dim_head=16,32,64,96,128 "
-             "kernels=l2norm,l2norm_pair,fwd(32 rows/wave; lean two-wave form at D=96/128),fwd2(64 rows/wave),fwd_ksplit(128 rows, wave halves split the keys),fwd_split+combine,"
+             "kernels=l2norm,l2norm_pair,fwd(32 rows/wave; lean two-wave form at D=96/128),fwd2(64 rows/wave),fwd3(D=128: 64 rows/wave, 1 wave/SIMD),fwd_ksplit(128 rows, wave halves split the keys),fwd_split+combine,"
              "fwd_dyn(per-row shift),bwd_dq(+split-key; key-split form on 8 waves),bwd_dkv(+lean; query-split form on 8 waves),bwd_dbias,finalize",
              FCSA_ABI_VERSION);
   }
