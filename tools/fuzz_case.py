@@ -6,6 +6,7 @@ import ast, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))      # `cases` (tests/conftest.py does this under pytest)
+sys.path.insert(0, os.path.join(ROOT, "tests"))                # `tolerances`
 from tests.test_gpu_fuzz import evaluate
 
 for text in sys.argv[1:]:
