@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (round 4): the -DFCSA_* form switches this script builds variants with were removed from the product sources in round 5 (they
+# are named constants in the .hip files now).  It documents how profiles/r04_ab_*.txt were produced -- check out the round-4 tree
+# (commit 8243d98) to re-run it.
 # Round 4 evidence: the same-process A/Bs behind the kernel decisions of the round.  Two steps:
 #   tools/gpu_ab_round4.sh build     (build container: development variants, bf16 D = 64 / 128 only, seconds each)
 #   tools/gpu_ab_round4.sh run       (GPU box: writes gpurun_out/r04_*.txt; copy them to profiles/)
