@@ -353,19 +353,26 @@ def main():
             # gfx950 correction) -- but ONLY if it was taken on the very library binary that is loaded now (sha256 recorded by
             # the PMC run); after any kernel change it reads null until the PMC passes are repeated.
             import glob
-            sha, hit = lib_sha256(), None
+            src, hit = _lib.source_sha256(), None
             for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
                 rec = json.load(open(tfile))
                 tk = rec.get("kernels", {}).get(dom["name"] + "_kernel")
-                if tk and rec.get("lib_sha256") == sha:
-                    hit = (os.path.relpath(tfile, ROOT), tk)
+                if tk and rec.get("src_sha256") == src:
+                    hit = (os.path.relpath(tfile, ROOT), tk, rec.get("derived", {}).get(dom["name"] + "_kernel"))
                     break
             if hit:
                 roofline["traffic"] = round(hit[1]["total_bytes"])
-                roofline["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; same libfcsa_hip.so sha256 %s)"
-                                              % (hit[0], sha[:12]))
+                roofline["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; measured on a build of the same "
+                                              "kernel sources + Makefile, source sha256 %s)" % (hit[0], src[:12]))
+                if hit[2]:      # matrix-pipe occupancy and effective clock of the same PMC passes (tools/pmc_summary.py)
+                    roofline["mfma_busy"] = hit[2].get("mfma_busy")
+                    roofline["effective_clock_ghz"] = hit[2].get("effective_clock_ghz")
+                    roofline["mfma_busy_what"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE per XCD), effective clock = GRBM_GUI_ACTIVE "
+                                                  "per XCD / kernel duration of the rocprofv3 kernel trace: the pipe's occupancy in REAL clocks next to `frac`, "
+                                                  "which prices the same launch against the 2.4 GHz nominal peak")
             else:
-                roofline["traffic_source"] = "null: no profiles/r*_pmc_traffic.json was measured on this build of libfcsa_hip.so (sha256 %s)" % sha[:12]
+                roofline["traffic_source"] = ("null: no profiles/r*_pmc_traffic.json was measured on these kernel sources (source sha256 %s; "
+                                              "library sha256 %s)" % (src[:12], lib_sha256()[:12]))
 
     # ---- stock softmax flash attention on the same box, shape, dtype, causal flag (the ">= 1.2x" target) -------
     sdpa = None

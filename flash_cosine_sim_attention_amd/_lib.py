@@ -81,7 +81,7 @@ KernelStat = _STRUCTS["fcsa_kernel_stat"]
 
 
 EXPORTS = ("fcsa_forward", "fcsa_backward", "fcsa_backward_workspace_bytes", "fcsa_forward_workspace_bytes", "fcsa_forward_needs_qn",
-           "fcsa_l2norm", "fcsa_debug", "fcsa_last_error", "fcsa_profile_enable", "fcsa_profile_collect")
+           "fcsa_l2norm", "fcsa_debug", "fcsa_debug_forward_form", "fcsa_last_error", "fcsa_profile_enable", "fcsa_profile_collect")
 
 _lib = None
 
@@ -124,6 +124,8 @@ def load():
     lib.fcsa_l2norm.restype = C.c_int
     lib.fcsa_debug.argtypes = [C.c_char_p, C.c_size_t]
     lib.fcsa_debug.restype = C.c_int
+    lib.fcsa_debug_forward_form.argtypes = [C.c_int32]
+    lib.fcsa_debug_forward_form.restype = C.c_int
     lib.fcsa_profile_enable.argtypes = [C.c_int32]
     lib.fcsa_profile_enable.restype = C.c_int
     lib.fcsa_profile_collect.argtypes = [C.POINTER(KernelStat), C.c_int32]
@@ -141,6 +143,27 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().fcsa_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (status {rc}): {msg}")
+
+
+def forward_form(form: int) -> int:
+    """Debug knob of the C ABI (include/fcsa.h, fcsa_debug_forward_form): 1 = automatic, 0 = never the 64-rows-per-wave D = 128
+    forward, < 0 = query.  Returns the previous setting.  (Applies to the library THIS module loaded -- the one the compiled binding
+    links, unless FCSA_LIB / fcsa_torch_use_library routed the ops elsewhere.)"""
+    return int(load().fcsa_debug_forward_form(int(form)))
+
+
+def source_sha256() -> str:
+    """sha256 over the kernel sources and the build recipe (csrc/*.hip, *.cuh, *.h, Makefile, include/fcsa.h; names and bytes, sorted):
+    what measurement files in profiles/ are keyed on.  The library BINARY is not reproducible bit for bit (two clean builds of one
+    tree differ in a few bytes), so a hash of the .so would orphan every committed measurement at the first rebuild."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cuh", ".h", ".cpp")) or f == "Makefile"]
+    files.append(HEADER)
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def profile_enable(on: bool):

@@ -290,6 +290,8 @@ int fcsa_debug(char* buf, size_t buf_bytes) {
   return FCSA_ABI_VERSION;
 }
 
+int fcsa_debug_forward_form(int32_t form) { return fcsa::forward_wide128_mode(form); }
+
 int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_t dim_head, int32_t groups,
                 const fcsa_tensor* x, void* xn, float* inv_norm, void* stream) {
   if (dtype != FCSA_F16 && dtype != FCSA_BF16 && dtype != FCSA_F32) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dtype %d not supported", dtype);

@@ -580,12 +580,23 @@ static hipError_t launch_fwd3_t(const FwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Escape hatch (same-process A/B, triage): 0 = never take this form.  The environment is read ONCE, when the library is loaded
+// (FCSA_FWD_WIDE128=0); afterwards only fcsa_debug_forward_form (include/fcsa.h) changes it -- no getenv on the launch path.
+static int wide128_env_default() {
+  const char* e = std::getenv("FCSA_FWD_WIDE128");
+  return (e != nullptr && e[0] == '0') ? 0 : 1;
+}
+static std::atomic<int> g_wide128{wide128_env_default()};
+int forward_wide128_mode(int set) {      // set < 0: query only; returns the previous value
+  return set < 0 ? g_wide128.load(std::memory_order_relaxed) : g_wide128.exchange(set != 0 ? 1 : 0, std::memory_order_relaxed);
+}
+
 // Does this problem take the form above?  16-bit D = 128, static exponent shift, no bias, no key mask, no key split, a grid of 256-row
 // (causal: paired) workgroups that covers the chip, K / V slices addressable with 32-bit offsets.
 bool use_forward_wide128(int dtype, int D, const FwdParams& p) {
   if (D != 128 || (dtype != 1 && dtype != 2)) return false;
   if (p.bias != nullptr || p.mask != nullptr || p.dyn || p.splits > 1) return false;
-  if (const char* e = std::getenv("FCSA_FWD_WIDE128"); e != nullptr && e[0] == '0') return false;      // escape hatch (A/B, triage)
+  if (g_wide128.load(std::memory_order_relaxed) == 0) return false;
   const int MT = (p.N + 255) / 256;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
   if (wgs < cu_count() * 7 / 8) return false;

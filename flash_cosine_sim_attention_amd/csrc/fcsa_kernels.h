@@ -97,20 +97,28 @@ static inline hipError_t ensure_dynamic_lds(K kern, size_t lds, std::atomic<uint
   return e;
 }
 
-// Compute units of the device the launch heuristics are sized for: queried ONCE per process (the current device at the first call; a
-// node's devices are alike), 256 when no device answers (host-only callers: workspace-size queries in the CPU tests).  Every "does
-// this grid cover the chip" threshold of the launchers and of the C ABI's split rules is a multiple of this number, so the workspace
-// size a caller is told and the launch that uses it always agree.
+// Compute units of the CURRENT device: what every "does this grid cover the chip" threshold of the launchers and of the C ABI's split
+// rules is a multiple of.  Cached per device id (a process may drive unlike devices, e.g. partitioned CPX modes); a query that fails is
+// answered with 256 and NOT remembered (host-only callers: workspace-size queries in the CPU tests; a process that asks before its
+// device is usable gets the real number the next time).  The workspace size a caller is told and the launch that uses it agree as long
+// as both run with the same current device.
 inline int cu_count() {
-  static std::atomic<int> cached{0};
-  int n = cached.load(std::memory_order_relaxed);
-  if (n > 0) return n;
+  static std::atomic<int> cached[64];
   int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+  if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();      // a host without a device: do not leave a sticky error behind
-    cus = 256;
+    return 256;
   }
-  cached.store(cus, std::memory_order_relaxed);
+  const bool slot = dev >= 0 && dev < 64;
+  if (slot) {
+    const int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+  }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  if (slot) cached[dev].store(cus, std::memory_order_relaxed);
   return cus;
 }
 
@@ -118,6 +126,7 @@ inline int cu_count() {
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s);
 // fcsa_fwd3.hip: the 64-rows-per-wave, one-wave-per-SIMD forward for 16-bit D = 128 (launch_forward dispatches to it)
 bool use_forward_wide128(int dtype, int D, const FwdParams& p);
+int forward_wide128_mode(int set);      // debug knob behind fcsa_debug_forward_form: set < 0 queries; returns the previous value
 hipError_t launch_forward_wide128(int dtype, const FwdParams& p, hipStream_t s);
 hipError_t launch_backward_dq(int dtype, int D, const BwdParams& p, hipStream_t s);
 hipError_t launch_backward_dbias(int dtype, int D, const BwdParams& p, hipStream_t s);   // d_bias from recomputed dS tiles (after dq: needs delta)

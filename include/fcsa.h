@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FCSA_ABI_VERSION 3
+#define FCSA_ABI_VERSION 4
 
 enum fcsa_status {
   FCSA_OK = 0,
@@ -205,6 +205,15 @@ typedef struct fcsa_kernel_stat {
 } fcsa_kernel_stat;
 int fcsa_profile_enable(int32_t enable);
 int fcsa_profile_collect(fcsa_kernel_stat* stats, int32_t capacity);
+
+/* Debug knob (same-process A/B runs and triage; no reference counterpart): which forward form 16-bit D = 128 problems may take.
+ * form = 1: automatic (the 64-rows-per-wave kernel of csrc/fcsa_fwd3.hip where its dispatch rule applies -- the default);
+ * form = 0: never that kernel (the 32-rows-per-wave forms instead); form < 0: query only.  Returns the previous setting.
+ * The initial value comes from the environment variable FCSA_FWD_WIDE128 ("0" = form 0), read ONCE when the library is loaded;
+ * no entry point reads the environment afterwards.  The two forms agree to one ulp of the 16-bit output (row sums of the
+ * un-rounded vs the rounded P~: DESIGN.md section 5), so results are form-dependent at that level; callers that need
+ * form-independent bits pin the form with this call. */
+int fcsa_debug_forward_form(int32_t form);
 
 /* Message for the last non-OK status returned on this thread ("" if none). */
 const char* fcsa_last_error(void);

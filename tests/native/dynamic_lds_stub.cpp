@@ -60,10 +60,18 @@ int main() {
   // hipGetDevice failing is passed through
   g_get_device_fails = 1;
   CHECK(ensure_dynamic_lds(&kernel_stub, 65536, other) == hipErrorNoDevice);
-  // cu_count: a host without a device answers 256 and caches it; (a fresh process with a device reports that device's count:
-  // tests/test_dynamic_lds_mask_cpu.py runs this binary a second time with FCSA_STUB_CUS)
-  if (const char* e = std::getenv("FCSA_STUB_CUS")) { g_get_device_fails = 0; g_cus = std::atoi(e); CHECK(fcsa::cu_count() == g_cus); g_cus = 1; CHECK(fcsa::cu_count() == std::atoi(e)); }
-  else { CHECK(fcsa::cu_count() == 256); g_get_device_fails = 0; g_cus = 304; CHECK(fcsa::cu_count() == 256); }
+  // cu_count: a host without a device answers 256 and does NOT remember it; a device's count is cached per device id
+  // (tests/test_dynamic_lds_mask_cpu.py runs this binary a second time with FCSA_STUB_CUS)
+  if (const char* e = std::getenv("FCSA_STUB_CUS")) {
+    g_get_device_fails = 0; g_device = 0; g_cus = std::atoi(e); CHECK(fcsa::cu_count() == g_cus);
+    g_cus = 1; CHECK(fcsa::cu_count() == std::atoi(e));                  // device 0: cached
+    g_device = 3; g_cus = 64; CHECK(fcsa::cu_count() == 64);            // another device of the process: its own answer
+    g_device = 0; CHECK(fcsa::cu_count() == std::atoi(e));
+  } else {
+    CHECK(fcsa::cu_count() == 256);                                      // no device: the fallback ...
+    g_get_device_fails = 0; g_device = 0; g_cus = 304; CHECK(fcsa::cu_count() == 304);      // ... is not cached
+    g_get_device_fails = 1; CHECK(fcsa::cu_count() == 256);
+  }
   std::printf("OK %zu set-attribute calls\n", g_set_calls.size());
   return 0;
 }

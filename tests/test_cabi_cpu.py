@@ -199,8 +199,31 @@ def test_forward_workspace_formula(lib):
 def test_debug_string(lib):
     buf = C.create_string_buffer(512)
     from flash_cosine_sim_attention_amd import _lib
-    assert lib.fcsa_debug(buf, 512) == _lib.ABI_VERSION == 3          # FCSA_ABI_VERSION (include/fcsa.h)
+    assert lib.fcsa_debug(buf, 512) == _lib.ABI_VERSION == 4          # FCSA_ABI_VERSION (include/fcsa.h)
     assert b"gfx950" in buf.value and b"bf16" in buf.value
+
+
+def test_debug_forward_form_knob(lib):
+    """fcsa_debug_forward_form (include/fcsa.h): set / query, returns the previous value; no device needed.  The library reads
+    FCSA_FWD_WIDE128 once at load and never again (no getenv on the launch path: round-5 review)."""
+    prev = lib.fcsa_debug_forward_form(-1)
+    assert prev in (0, 1)
+    assert lib.fcsa_debug_forward_form(0) == prev
+    assert lib.fcsa_debug_forward_form(-1) == 0
+    assert lib.fcsa_debug_forward_form(7) == 0          # any non-zero value means "automatic"
+    assert lib.fcsa_debug_forward_form(-1) == 1
+    lib.fcsa_debug_forward_form(prev)
+    import os, subprocess, sys
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flash_cosine_sim_attention_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".cuh", ".h")):
+            text = open(os.path.join(src, f)).read()
+            assert text.count("getenv(") <= (1 if f == "fcsa_fwd3.hip" else 0), f"{f}: getenv outside the load-time initialiser"
+    # the environment is honoured at LOAD time: a fresh process with FCSA_FWD_WIDE128=0 starts at form 0
+    code = "from flash_cosine_sim_attention_amd import _lib; print(_lib.forward_form(-1))"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(os.environ, FCSA_FWD_WIDE128="0"), timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr
 
 
 def test_gpu_entry_points_reject_cpu_tensors():

@@ -16,7 +16,7 @@ import json
 import os
 
 #            atol,  rtol (one output ulp), rel-L2 of the forward output
-# Round 5 calibration (profiles/r05_tolerance_margins.txt, all 1531 GPU tests logged): worst measured over the suite ->
+# Round 5 calibration (profiles/r05_tolerance_margins.txt, all 1331 GPU tests logged): worst measured over the suite ->
 #   forward rel-L2   bf16 4.09e-3 (x_n200_d16_causal: D = 16, 200 keys)   f16 5.74e-4   f32 2.13e-6
 #   forward excess   bf16 0.75 of the bar   f16 1.56e-3 (of 5e-3)   f32 6.3e-6 (of 2e-5)
 #   gradient rel-L2  bf16 5.8e-3 (K28 D = 16 causal; 5.2e-3 on the reference grid)   f16 9.0e-4   f32 2.0e-6 (2.4e-5 at scale 120, its own bar)

@@ -1,4 +1,4 @@
-"""Interleaved same-process A/B of the D = 128 forward forms: FCSA_FWD_WIDE128 is read per launch (fcsa_fwd3.hip), so one process times
+"""Interleaved same-process A/B of the D = 128 forward forms: the C ABI's debug knob fcsa_debug_forward_form (include/fcsa.h) switches the form between launches, so one process times
 the lean 32-row form ("0") and the product's wide form ("").  (The development snapshots of round 5 -- commit "fcsa_fwd3 v2-v5" -- also
 understood ring depths, row-sum forms and ablations: "r3", "r4d", "rx" ...; the tables they produced are profiles/r05_fwd3_ab_v*.txt,
 r05_fwd3_ablations_v*.txt.)  HIP-event timing of forward-only calls under no_grad, `rounds` interleaved rounds of `iters`.
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     args = ap.parse_args()
     import flash_cosine_sim_attention_amd as F
+    from flash_cosine_sim_attention_amd import _lib
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     print("device:", torch.cuda.get_device_name(0), "dtype:", args.dtype)
     for shp in args.shapes:
@@ -38,10 +39,7 @@ def main():
         with torch.no_grad():
             for r in range(args.rounds + 1):
                 for vn in args.variants:
-                    if vn and vn != "on":
-                        os.environ["FCSA_FWD_WIDE128"] = vn
-                    else:
-                        os.environ.pop("FCSA_FWD_WIDE128", None)
+                    _lib.forward_form(0 if vn == "0" else 1)
                     for _ in range(5):
                         o = F.flash_cosine_sim_attention(q, k, v, causal=bool(causal))
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,7 +51,7 @@ def main():
                     if r > 0:                                   # round 0 = warm-up
                         times[vn].append(s.elapsed_time(e) / args.iters * 1e3)
                     outs[vn] = o
-        os.environ.pop("FCSA_FWD_WIDE128", None)
+        _lib.forward_form(1)
         base = outs[args.variants[0]].float()
         print(f"== (B,H,N,M)=({B},{H},{N},{M}) causal={causal}  {flops / 1e9:.1f} GFLOP")
         for vn in args.variants:

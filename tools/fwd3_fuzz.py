@@ -1,6 +1,6 @@
 """Differential fuzz of the D = 128 wide forward (csrc/fcsa_fwd3.hip) against the lean 32-row form it replaces: random shapes that the
 dispatch sends to it (16-bit, D = 128, no bias / mask, grid >= 7/8 of the CUs), random causal / N != M / ragged sizes / single-headed K/V /
-groups / scale / l2norm_qk / strided views / inference vs training, both forms run in ONE process (FCSA_FWD_WIDE128 is read per launch).
+groups / scale / l2norm_qk / strided views / inference vs training, both forms run in ONE process (fcsa_debug_forward_form, include/fcsa.h, switches between launches).
 The outputs may differ by the rounding of the 16-bit output (the forms sum rows and P~ in different orders): any element further apart
 than one output ulp, any non-finite value and any inv_l further apart than 1e-5 relative is reported with the configuration.
 usage: python tools/fwd3_fuzz.py [--seed S] [--n 200]"""
@@ -34,6 +34,7 @@ def draw(rs):
 
 def run(cfg, seed):
     import flash_cosine_sim_attention_amd as F
+    from flash_cosine_sim_attention_amd import _lib
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[cfg["dtype"]]
     g = torch.Generator(device="cuda").manual_seed(seed)
     B, H, N, M, D = cfg["B"], cfg["H"], cfg["N"], cfg["M"], 128
@@ -53,10 +54,7 @@ def run(cfg, seed):
     kw = dict(scale=scale, groups=groups, causal=cfg["causal"], l2norm_qk=cfg["l2norm"])
     outs = []
     for form in ("on", "0"):
-        if form == "0":
-            os.environ["FCSA_FWD_WIDE128"] = "0"
-        else:
-            os.environ.pop("FCSA_FWD_WIDE128", None)
+        _lib.forward_form(0 if form == "0" else 1)
         if cfg["grad"]:
             qq, kk, vv = (t.detach().clone().requires_grad_() for t in (q, k, v))
             o = F.flash_cosine_sim_attention(qq, kk, vv, **kw)
@@ -65,7 +63,7 @@ def run(cfg, seed):
         else:
             with torch.no_grad():
                 outs.append((F.flash_cosine_sim_attention(q, k, v, **kw),))
-    os.environ.pop("FCSA_FWD_WIDE128", None)
+    _lib.forward_form(1)
     torch.cuda.synchronize()
     ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
     new, old = outs
