@@ -25,7 +25,7 @@ import numpy as np
 __all__ = [
     "l2norm", "l2norm_backward", "plain_attention", "tiled_attention",
     "attention_forward_stats", "attention_backward", "causal_valid_count",
-    "algorithmic_flops", "round_to", "rounded_operands",
+    "algorithmic_flops", "round_to", "rounded_operands", "attention_backward_emulated",
 ]
 
 LOG2E = 1.4426950408889634
@@ -345,6 +345,120 @@ def attention_backward(do, q, k, v, mask=None, attn_bias=None, scale=8, groups=1
     dk = dk.reshape(k0.shape)
     dv = dv.reshape(v0.shape)
     return dq, dk, dv, dbias
+
+
+# ----------------------------------------------------------------------------
+# working-precision model of the gfx950 kernels (what a CORRECT float32-accumulating implementation with their rounding points returns)
+# ----------------------------------------------------------------------------
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def _seq_matmul_f32(a, b, chunk=16):
+    """a[..., i, c] @ b[..., c, j] in float32 with the contraction index consumed SEQUENTIALLY in chunks of `chunk` (one MFMA k-step:
+    products of a chunk summed, then added to the float32 accumulator) -- no pairwise / blocked re-association of the long sum."""
+    a, b = _f32(a), _f32(b)
+    n = a.shape[-1]
+    acc = np.zeros(np.broadcast_shapes(a.shape[:-2], b.shape[:-2]) + (a.shape[-2], b.shape[-1]), dtype=np.float32)
+    for c0 in range(0, n, chunk):
+        acc = (acc + np.matmul(a[..., :, c0:c0 + chunk], b[..., c0:c0 + chunk, :])).astype(np.float32)
+    return acc
+
+
+def attention_backward_emulated(do, q, k, v, storage, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
+                                l2norm_qk=True, attn_bias_batch_dim=False):
+    """(o, dq, dk, dv, d_bias) as a float32-ACCUMULATING implementation with the rounding points of the gfx950 kernels computes them
+    (DESIGN.md sections 2, 4.1): inputs, the saved c1 * q^ / k^ and every output in `storage` ("f32" | "f16" | "bf16"); S, P~, row
+    sums, delta, dP, dS, every accumulator and the l2norm backward in float32, long sums taken sequentially (`_seq_matmul_f32`); P and dS
+    rounded to `storage` in front of the second products (16-bit types).  This is NOT a checker of the kernels' values -- their
+    summation order differs -- but of the SIZE of the error such arithmetic leaves on a given problem:
+        err_model = || emulated - float64 || / || float64 ||
+    is what `tests/test_gpu_fuzz.py` derives the allowance of its ill-conditioned classes from (few query rows: dq / dk / d_bias are
+    one row's cancellation residue of dP - delta; a handful of keys under many rows: dk sums every row's rounding of dP - delta), instead
+    of hand-set factors (round-5 review: "verify the allowances instead of explaining them").  Reference formulas: cu:1256-1626.
+    """
+    assert not (causal and mask is not None)
+    st = storage
+    rnd = (lambda x: _f32(x)) if st == "f32" else (lambda x: round_to(x, st).astype(np.float32))
+    q0, k0, v0, do0 = (_f32(round_to(t, st)) for t in (q, k, v, do))
+    bias0 = None if attn_bias is None else _f32(round_to(attn_bias, st))
+    qc, kc, vc, bias, merged = _canon(q0, k0, v0, bias0, attn_bias_batch_dim)
+    if merged:
+        do0 = do0[:, None]
+        attn_bias_batch_dim = True
+    b, h, n, d = qc.shape
+    m, hk = kc.shape[2], kc.shape[1]
+    c1 = np.float32(scale * LOG2E)
+
+    def norm32(x):      # grouped l2norm in float32: x / max(||x_g||, 1e-12), inverse norms
+        xg = x.reshape(*x.shape[:-1], groups, d // groups)
+        ss = np.zeros(xg.shape[:-1], dtype=np.float32)
+        for e in range(xg.shape[-1]):
+            ss = (ss + xg[..., e] * xg[..., e]).astype(np.float32)
+        r = (np.float32(1.0) / np.maximum(np.sqrt(ss), np.float32(1e-12))).astype(np.float32)
+        return (xg * r[..., None]).reshape(x.shape).astype(np.float32), r
+
+    if l2norm_qk:
+        qh, rq = norm32(qc)
+        kh, rk = norm32(kc)
+    else:
+        qh, kh, rq, rk = qc, kc, None, None
+    qn = rnd(qh * c1)                         # the saved c1 * q^ (one rounding), B operand of the S chains
+    kn = rnd(kh)
+    kb = np.broadcast_to(kn, (b, h, m, d))
+    vb = np.broadcast_to(vc, (b, h, m, d))
+    s2 = _seq_matmul_f32(qn, np.swapaxes(kb, -1, -2))                       # log2 units
+    if bias is not None:
+        s2 = (s2 + bias * np.float32(LOG2E)).astype(np.float32)
+    valid = np.broadcast_to(_valid_mask(n, m, causal, mask), s2.shape)
+    # forward: per-row reference = the row max (any shift gives the same o; the kernels use a constant or an online one)
+    ref = np.where(valid, s2, -np.inf).max(-1, keepdims=True)
+    ref = np.where(np.isfinite(ref), ref, 0).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        pt = np.where(valid, np.exp2((s2 - ref).astype(np.float32)), 0).astype(np.float32)
+    pt16 = rnd(pt)
+    l = pt16.sum(-1, dtype=np.float64).astype(np.float32)                   # exact f32 sum of the ROUNDED values (v_dot2c)
+    inv_l = (np.float32(1.0) / np.maximum(l, np.float32(1e-30))).astype(np.float32)
+    o = rnd(_seq_matmul_f32(pt16, vb) * inv_l[..., None])
+    lc = (np.log2(inv_l) - ref[..., 0]).astype(np.float32)                  # seed of the backward's S accumulators
+    # backward
+    delta = np.zeros((b, h, n), dtype=np.float32)
+    for e in range(d):
+        delta = (delta + do0[..., e] * o[..., e]).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        p = np.where(valid, np.exp2((s2 + lc[..., None]).astype(np.float32)), 0).astype(np.float32)
+    dp = (_seq_matmul_f32(do0, np.swapaxes(vb, -1, -2)) - delta[..., None]).astype(np.float32)
+    ds = (p * dp).astype(np.float32)
+    p16, ds16 = rnd(p), rnd(ds)
+    dv = _seq_matmul_f32(np.swapaxes(p16, -1, -2), do0)
+    dqh = (np.float32(scale) * _seq_matmul_f32(ds16, kb)).astype(np.float32)
+    dkh = (np.float32(scale / float(c1)) * _seq_matmul_f32(np.swapaxes(ds16, -1, -2), qn)).astype(np.float32)
+    if hk == 1 and h > 1:
+        dv = dv.sum(1, keepdims=True, dtype=np.float32)
+        dkh = dkh.sum(1, keepdims=True, dtype=np.float32)
+    dbias = None
+    if bias is not None:
+        dbias = rnd(ds.sum(1 if attn_bias_batch_dim else 0, dtype=np.float32))
+
+    def norm_bwd32(g, xhat, r):          # dx = r (g - x^ <g, x^>) per group, float32; x^ = the stored normalised rows
+        gg = g.reshape(*g.shape[:-1], groups, d // groups)
+        xg = xhat.reshape(gg.shape)
+        dot = np.zeros(gg.shape[:-1], dtype=np.float32)
+        for e in range(gg.shape[-1]):
+            dot = (dot + gg[..., e] * xg[..., e]).astype(np.float32)
+        out = (r[..., None] * (gg - xg * dot[..., None])).astype(np.float32)
+        out = np.where((r >= np.float32(1e12))[..., None], gg * r[..., None], out)
+        return out.reshape(g.shape)
+
+    if l2norm_qk:
+        dq = norm_bwd32(dqh, (qn / c1).astype(np.float32), rq)
+        dk = norm_bwd32(dkh, kn, rk)
+    else:
+        dq, dk = dqh, dkh
+    to64 = lambda x, ref_shape: rnd(x).astype(np.float64).reshape(ref_shape)
+    return (to64(o, np.asarray(q).shape), to64(dq, np.asarray(q).shape), to64(dk, np.asarray(k).shape), to64(dv, np.asarray(v).shape),
+            None if dbias is None else dbias.astype(np.float64))
 
 
 # ----------------------------------------------------------------------------

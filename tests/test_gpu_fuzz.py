@@ -116,6 +116,13 @@ def _npf(t):
     return t.detach().cpu().double().numpy()
 
 
+kModelSlack = 2.0      # a gradient of an ill-conditioned class may sit at this multiple of the working-precision model's error
+
+
+def _rel(gg, rr, floor_per_elem=1e-3):
+    return np.linalg.norm(gg - rr) / max(np.linalg.norm(rr), floor_per_elem * np.sqrt(rr.size))
+
+
 def evaluate(cfg, raw=True):
     """runs one configuration; yields (what, measured, limit) for the forward and every gradient (tools/fuzz_case.py prints them).
     raw = False: only the operand-faithful comparison (NAMED_CASES)"""
@@ -158,16 +165,14 @@ def evaluate(cfg, raw=True):
     eps = 1e-300 if dyn else 1e-10
     atol, rtol = FWD_TOL[cfg["dtype"]]
     cond = max(1.0, cfg["scale"] * cfg["groups"] / 16.0) if cfg["dtype"] != "f32" and cfg["l2norm"] else 1.0
-    # ONE or two query rows: the whole dq / dk / d_bias is a row's cancellation residue of dP - delta (the X11 class below), not an average
-    # over rows -- x 1.5 on the gradient bars (round 5, exploratory seeds 31 / 32 on the tightened bars: bf16 N = 1, 4-feature groups,
-    # scale * groups = 64: dq 4.3e-2 against 3.4e-2; f16 N = M = 1 d_bias 2.3e-3 against 2.1e-3, where the exact value is 0)
-    few_rows = 1.5 if N <= 2 else 1.0
-    # At most four keys under many rows: dk sums the rounding of every row's dP - delta (proportional to |dP|, also for the rows whose
-    # weight sits on one key and whose dS is nearly 0) against a signal that only the undecided rows carry -- exploratory seed 33, N = 2961,
-    # M = 3, key mask: dk 2.1e-3 bf16, 5.5e-3 f16 and 2.0e-4 in FLOAT32 (tools/fuzz_case.py: the f32 value is what marks it as conditioning,
-    # not a defect of a 16-bit path); dq and dv of the same run are at 1e-4 / 1e-6.  x 4 on the gradient bars of such problems (x 12 f32).
-    if M <= 4 and N >= 64:
-        few_rows = 12.0 if cfg["dtype"] == "f32" else 4.0
+    # Ill-conditioned classes -- ONE or two query rows (the whole dq / dk / d_bias is a row's cancellation residue of dP - delta, not an
+    # average over rows) and at most four keys under many rows (dk sums every row's rounding of dP - delta against a signal only the
+    # undecided rows carry): rounds 4 - 5 met them with hand-set factors on the bars (x 1.5, x 4, x 12 for float32).  Round 6 (review item
+    # 6) DERIVES the allowance instead: the oracle evaluates the same problem with float32 accumulation and the kernels' rounding points
+    # (`attention_backward_emulated`), and a gradient may be as far from float64 as max(stated bar, kModelSlack x that model's own error)
+    # -- per gradient, so a dq or dv regression on a problem whose dk is ill-conditioned does not hide behind dk's allowance.  A kernel
+    # error beyond that is a defect by construction of the model, not conditioning.
+    model_class = N <= 2 or (M <= 4 and N >= 64)
     for pr in pairs:
         if pr is None:
             sl_q = sl_k = (slice(None), slice(None))
@@ -191,15 +196,26 @@ def evaluate(cfg, raw=True):
             yield f"{pr}: forward excess (16-bit operands)", (np.abs(got - ro) - rtol * np.abs(ro)).max(), atol * max(vmax, 1.0)
             # (the backward's own input `o`: delta = rowsum(dO * o) is taken from the output the forward stored, oracle `o_saved`)
             grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], o_saved=got, **okw)
+            model = None
+            if model_class:      # the working-precision model of this very problem (same inputs, same slices)
+                em = O.attention_backward_emulated(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, cfg["dtype"], **{k_: v_ for k_, v_ in okw.items() if k_ != "eps"})
+                model = dict(zip(names, em[1:]))
             for name, gg, rr in zip(names, gots, grads):
-                rel = np.linalg.norm(gg - rr) / max(np.linalg.norm(rr), 1e-3 * np.sqrt(rr.size))
-                yield f"{pr}: {name} rel-L2 (16-bit operands)", rel, few_rows * GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
+                rel = _rel(gg, rr)
+                lim = GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
+                if model is not None:
+                    lim = max(lim, kModelSlack * _rel(model[name], rr))
+                yield f"{pr}: {name} rel-L2 (16-bit operands)", rel, lim
         if not raw:
             continue
         ro, _ = O.attention_forward_stats(_npf(q)[sl_q], kq, vq, **okw)
         excess = (np.abs(got - ro) - rtol * np.abs(ro)).max()
         yield f"{pr}: forward excess", excess, cond * atol * max(vmax, 1.0)
         grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, **okw)
+        model = None
+        if model_class:
+            em = O.attention_backward_emulated(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, cfg["dtype"], **{k_: v_ for k_, v_ in okw.items() if k_ != "eps"})
+            model = dict(zip(names, em[1:]))
         for name, gg, rr in zip(names, gots, grads):
             # the floor keeps the ratio meaningful when the exact gradient is (nearly) zero.  f32 additionally gets an ABSOLUTE
             # allowance: where P == 1 (N = M = 1, or one unmasked key) dS == P (dP - delta) == 0 exactly and the kernel returns the f32
@@ -211,7 +227,9 @@ def evaluate(cfg, raw=True):
             if cfg["dtype"] == "f32" and np.linalg.norm(rr) < floor and err <= 6e-6 * max(1.0, cfg["scale"] / 8.0) * np.sqrt(rr.size):
                 continue
             rel = err / max(np.linalg.norm(rr), floor)
-            lim = few_rows * cond * GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
+            lim = cond * GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
+            if model is not None:
+                lim = max(lim, kModelSlack * np.linalg.norm(model[name] - rr) / max(np.linalg.norm(rr), floor))
             yield f"{pr}: {name} rel-L2", rel, lim
 
 

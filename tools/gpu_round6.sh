@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-6 GPU sessions, by stage (one gpurun call runs a few of them).  usage: bash tools/gpu_round6.sh stage [stage ...]
+set -u
+export TMPDIR=/tmp
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out"; mkdir -p "$O"
+kstats() {   # kstats NAME ITERS: rocprofv3 kernel-trace stats of tools/run_config.py NAME -> $O/kstats_NAME.csv (our kernels only)
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ks_$1" -o k -- python "$R/tools/run_config.py" "$1" "$2" > "$O/ks_$1.log" 2>&1 )
+  f=$(find "$O/ks_$1" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && python - "$f" > "$O/kstats_$1.txt" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "fcsa::" in r["Name"]:
+        n = r["Name"].replace("void fcsa::", "").split("(")[0]
+        print(f"{n[:70]:70s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f}  max {float(r['MaxNs'])/1e3:8.2f}")
+PY
+  rm -rf "$O/ks_$1"; tail -n 1 "$O/ks_$1.log"; cat "$O/kstats_$1.txt" 2>/dev/null
+}
+for stage in "$@"; do
+  echo "=== stage $stage"
+  case "$stage" in
+    quick)    # the tests that exercise this round's host-side changes
+      timeout 900 python -m pytest tests/test_gpu_wide128.py tests/test_gpu_cabi_direct.py tests/test_gpu_misc.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -n 5 ;;
+    kstats)   # true (un-instrumented) kernel durations of the other configs
+      for n in C5 C2 C4 d128 d64; do kstats $n 60; done ;;
+    bench)
+      timeout 600 python bench.py > "$O/bench.log" 2>&1; tail -n 1 "$O/bench.log" > "$O/bench_line.json"; cut -c1-900 "$O/bench_line.json" ;;
+    breakdown)
+      timeout 300 python tools/kernel_breakdown.py d64 d128 C5 C4 C2 > "$O/breakdown.txt" 2>&1; grep -v amdgpu.ids "$O/breakdown.txt" ;;
+    suite)
+      python -c "import os, torch; n = torch.cuda.device_count(); print('torch.cuda.device_count() =', n, [torch.cuda.get_device_name(i) for i in range(n)], 'HIP_VISIBLE_DEVICES =', os.environ.get('HIP_VISIBLE_DEVICES'))" > "$O/pytest_gpu.log" 2>&1
+      FCSA_TOL_LOG="$O/tol_log.jsonl" timeout 2400 python -m pytest tests -m gpu -q --maxfail=50 -p no:cacheprovider >> "$O/pytest_gpu.log" 2>&1; tail -n 8 "$O/pytest_gpu.log"
+      python tools/tolerance_margins.py "$O/tol_log.jsonl" > "$O/tolerance_margins.txt" 2>&1; rm -f "$O/tol_log.jsonl" ;;
+    fuzz_explore)   # exploratory seeds of round 5 (31, 32, 33: 408 configurations beyond the committed 136) under the model-derived allowances
+      for sd in 31 32 33; do
+        FCSA_FUZZ_SEED=$sd timeout 1200 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -k random_config --maxfail=30 -p no:cacheprovider > "$O/fuzz_seed$sd.log" 2>&1
+        echo "seed $sd: $(tail -n 1 "$O/fuzz_seed$sd.log")"; grep "^FAILED\|AssertionError: {" "$O/fuzz_seed$sd.log" | cut -c1-600 | head -n 12
+      done ;;
+    fuzz)
+      timeout 1500 python -m pytest tests/test_gpu_fuzz.py -m gpu -q --maxfail=30 -p no:cacheprovider > "$O/fuzz.log" 2>&1; tail -n 3 "$O/fuzz.log"; grep "AssertionError: {" "$O/fuzz.log" | cut -c1-600 | head ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
