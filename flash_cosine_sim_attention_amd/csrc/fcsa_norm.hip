@@ -88,16 +88,17 @@ struct RowMap {
 // forward, group size multiple of 8
 // ---------------------------------------------------------------------------------------------
 constexpr int kNormUnroll = 4;      // row chunks per block: all loads of a thread are issued before the first use
-
-template <typename T>
+// Small tensors (single-headed K at C5: 8192 rows = 64 blocks of 4 chunks on 256 CUs) take one chunk per thread instead, so the grid
+// still reaches every CU: the pass is latency-bound there, not bandwidth-bound.
+template <typename T, int UNROLL = kNormUnroll>
 FCSA_DEV void l2norm_rows(const NormParams& p, int block) {
   const int64_t nrows = (int64_t)p.B * p.H * p.L;
   const int dg = p.D / p.G, lpg = dg >> 3;
-  RowMap m[kNormUnroll];
-  float f[kNormUnroll][8];
+  RowMap m[UNROLL];
+  float f[UNROLL][8];
 #pragma unroll
-  for (int u = 0; u < kNormUnroll; ++u) {
-    m[u].init(p.D, nrows, block * kNormUnroll + u);
+  for (int u = 0; u < UNROLL; ++u) {
+    m[u].init(p.D, nrows, block * UNROLL + u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
     if (m[u].active) {
@@ -107,7 +108,7 @@ FCSA_DEV void l2norm_rows(const NormParams& p, int block) {
     }
   }
 #pragma unroll
-  for (int u = 0; u < kNormUnroll; ++u) {
+  for (int u = 0; u < UNROLL; ++u) {
     float ss = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ss += f[u][e] * f[u][e];
@@ -122,8 +123,8 @@ FCSA_DEV void l2norm_rows(const NormParams& p, int block) {
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) { l2norm_rows<T>(p, blockIdx.x); }
+template <typename T, int UNROLL = kNormUnroll>
+__global__ void __launch_bounds__(256) l2norm_kernel(const NormParams p) { l2norm_rows<T, UNROLL>(p, blockIdx.x); }
 
 // q and k of one attention call in ONE grid (both are short HBM-bound passes; a second launch costs
 // about as much as the pass itself): blocks [0, blocks_a) take `a`, the rest take `b`.
@@ -172,14 +173,34 @@ FCSA_DEV void l2norm_bwd_rows(const NormBwdParams& p, int block) {
   if (m.active) {
     split_row(m.row, nrows, p.L, p.HO, b, h, l);
     const int nsum = (p.HS == p.HO) ? 1 : p.HS;
-    for (int hs = 0; hs < nsum; ++hs) {
-      const int64_t srow = ((int64_t)b * p.HS + (p.HS == p.HO ? h : hs)) * p.L + l;
-      if (p.slab_f32) {
-        const f32x4* s = reinterpret_cast<const f32x4*>(p.slab + (srow * p.D + m.c * 8) * 4);
-        const f32x4 a = s[0], c = s[1];
+    if (p.slab_f32) {
+      // f32 slabs: the loads of FOUR slabs (8 x 16 bytes per lane) are issued before the first add -- the head loop is the whole kernel
+      // (single-headed K/V at C5: 8 slabs of 33.5 MB each way), and one slab per iteration left a single dependent load pair in flight
+      const int64_t hstride = (int64_t)p.L * p.D * 4;
+      const char* s0 = p.slab + ((((int64_t)b * p.HS + (p.HS == p.HO ? h : 0)) * p.L + l) * p.D + m.c * 8) * 4;
+      int hs = 0;
+      for (; hs + 4 <= nsum; hs += 4) {
+        f32x4 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4* sp = reinterpret_cast<const f32x4*>(s0 + (hs + u) * hstride);
+          a[u] = sp[0];      // (plain loads: the slabs were written by the previous kernel and are still on chip; nontemporal loads
+          c[u] = sp[1];      //  measured 15.4 vs 14.7 us at C5, profiles/r06_ab_norm.txt)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { g[e] += a[u][e]; g[4 + e] += c[u][e]; }
+      }
+      for (; hs < nsum; ++hs) {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(s0 + hs * hstride);
+        const f32x4 a = sp[0], c = sp[1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { g[e] += a[e]; g[4 + e] += c[e]; }
-      } else {
+      }
+    } else {
+      for (int hs = 0; hs < nsum; ++hs) {
+        const int64_t srow = ((int64_t)b * p.HS + (p.HS == p.HO ? h : hs)) * p.L + l;
         float t[8];
         load8<T>(p.slab + (srow * p.D + m.c * 8) * Traits<T>::ES, t);
 #pragma unroll
@@ -265,8 +286,14 @@ static hipError_t launch_l2norm_t(const NormParams& p, hipStream_t s) {
   if (nrows == 0) return hipSuccess;
   const int dg = p.D / p.G;
   if (dg % 8 == 0) {
-    const int rows_per_block = kNormUnroll * 4 * (64 / (p.D / 8));
-    hipLaunchKernelGGL(l2norm_kernel<T>, dim3((unsigned)((nrows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, p);
+    const int rows_per_wave_pass = 4 * (64 / (p.D / 8));
+    const int rows_per_block = kNormUnroll * rows_per_wave_pass;
+    const int64_t blocks = (nrows + rows_per_block - 1) / rows_per_block;
+    if (blocks < 2 * cu_count()) {      // a grid that would leave CUs idle: one chunk per thread
+      hipLaunchKernelGGL((l2norm_kernel<T, 1>), dim3((unsigned)((nrows + rows_per_wave_pass - 1) / rows_per_wave_pass)), dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL(l2norm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
   } else {
     const int64_t total = nrows * p.G;
     hipLaunchKernelGGL(l2norm_generic_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);

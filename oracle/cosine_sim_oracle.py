@@ -367,7 +367,7 @@ def _seq_matmul_f32(a, b, chunk=16):
 
 
 def attention_backward_emulated(do, q, k, v, storage, mask=None, attn_bias=None, scale=8, groups=1, causal=False,
-                                l2norm_qk=True, attn_bias_batch_dim=False):
+                                l2norm_qk=True, attn_bias_batch_dim=False, o_saved=None):
     """(o, dq, dk, dv, d_bias) as a float32-ACCUMULATING implementation with the rounding points of the gfx950 kernels computes them
     (DESIGN.md sections 2, 4.1): inputs, the saved c1 * q^ / k^ and every output in `storage` ("f32" | "f16" | "bf16"); S, P~, row
     sums, delta, dP, dS, every accumulator and the l2norm backward in float32, long sums taken sequentially (`_seq_matmul_f32`); P and dS
@@ -377,6 +377,10 @@ def attention_backward_emulated(do, q, k, v, storage, mask=None, attn_bias=None,
     is what `tests/test_gpu_fuzz.py` derives the allowance of its ill-conditioned classes from (few query rows: dq / dk / d_bias are
     one row's cancellation residue of dP - delta; a handful of keys under many rows: dk sums every row's rounding of dP - delta), instead
     of hand-set factors (round-5 review: "verify the allowances instead of explaining them").  Reference formulas: cu:1256-1626.
+    o_saved: the stored output the backward is GIVEN (`o` is an input of the reference's backward, cu:1752-1764; delta = rowsum(dO * o) is
+    taken from it, cu:1256-1335).  Where dP - delta cancels, WHICH way the 16-bit elements of `o` were rounded decides the residue: a
+    one-row problem measured 3 - 5e-2 between two correct implementations whose stored outputs differ by one bf16 ulp in a few elements
+    (profiles/r06_fuzz_model_probe.txt).  Given, the model's backward uses it, like `attention_backward` does; the returned o is the model's own.
     """
     assert not (causal and mask is not None)
     st = storage
@@ -423,9 +427,10 @@ def attention_backward_emulated(do, q, k, v, storage, mask=None, attn_bias=None,
     o = rnd(_seq_matmul_f32(pt16, vb) * inv_l[..., None])
     lc = (np.log2(inv_l) - ref[..., 0]).astype(np.float32)                  # seed of the backward's S accumulators
     # backward
+    o_used = o if o_saved is None else _f32(round_to(o_saved, st)).reshape(o.shape)
     delta = np.zeros((b, h, n), dtype=np.float32)
     for e in range(d):
-        delta = (delta + do0[..., e] * o[..., e]).astype(np.float32)
+        delta = (delta + do0[..., e] * o_used[..., e]).astype(np.float32)
     with np.errstate(over="ignore", invalid="ignore"):
         p = np.where(valid, np.exp2((s2 + lc[..., None]).astype(np.float32)), 0).astype(np.float32)
     dp = (_seq_matmul_f32(do0, np.swapaxes(vb, -1, -2)) - delta[..., None]).astype(np.float32)

@@ -12,6 +12,8 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--shape", default="4,8,4096,64,1", help="B,H,N,D,causal[,M[,bias[,mask]]]; several shapes separated by ':'")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--scale", type=float, default=8.0)
+ap.add_argument("--groups", type=int, default=1)
+ap.add_argument("--single-kv", action="store_true", help="k, v of shape (B, M, D): single-headed K/V (C5)")
 ap.add_argument("tags", nargs="+")
 a = ap.parse_args()
 import ctypes
@@ -38,7 +40,8 @@ def run_shape(shape):
     mask = (torch.rand(B, M, device="cuda") > 0.25) if with_mask else None
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     q = torch.randn(B, H, N, D, device="cuda", dtype=dt, requires_grad=True)
-    k, v = (torch.randn(B, H, M, D, device="cuda", dtype=dt, requires_grad=True) for _ in range(2))
+    kshape = (B, M, D) if a.single_kv else (B, H, M, D)
+    k, v = (torch.randn(kshape, device="cuda", dtype=dt, requires_grad=True) for _ in range(2))
     do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
     bias = (0.5 * torch.randn(H, N, M, device="cuda")).to(dt).requires_grad_() if with_bias else None
     if os.environ.get("FCSA_AB_FILL"):      # constant inputs: no operand bits toggle -- how much of the time is the power limit?
@@ -47,7 +50,7 @@ def run_shape(shape):
     def step():
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale).backward(do)
+        F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale, groups=a.groups).backward(do)
     res = {t: {} for t in a.tags}
     for r in range(a.rounds + 1):
         for t in a.tags:
@@ -69,7 +72,7 @@ def run_shape(shape):
         assert binding.fcsa_torch_use_library(paths[t].encode()) == 0, t
         q.grad = k.grad = v.grad = None
         if bias is not None: bias.grad = None
-        o = F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale)
+        o = F.flash_cosine_sim_attention(q, k, v, mask=mask, attn_bias=bias, causal=bool(causal), scale=a.scale, groups=a.groups)
         o.backward(do)
         outs[t] = [x.detach().float().clone() for x in (o, q.grad, k.grad, v.grad) + ((bias.grad,) if bias is not None else ())]
     for t in a.tags[1:]:

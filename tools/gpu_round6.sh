@@ -37,6 +37,12 @@ for stage in "$@"; do
       done ;;
     fuzz)
       timeout 1500 python -m pytest tests/test_gpu_fuzz.py -m gpu -q --maxfail=30 -p no:cacheprovider > "$O/fuzz.log" 2>&1; tail -n 3 "$O/fuzz.log"; grep "AssertionError: {" "$O/fuzz.log" | cut -c1-600 | head ;;
+    probe_L02)
+      timeout 300 python tools/fuzz_model_probe.py "{'id': 'L02', 'dtype': 'bf16', 'B': 1, 'H': 3, 'N': 1, 'M': 3283, 'D': 16, 'causal': False, 'mask': True, 'bias': False, 'bias_batch': True, 'single_kv': False, 'groups': 4, 'l2norm': True, 'scale': 16.0, 'seed': 758000559}" "{'id': 'L21', 'dtype': 'f16', 'B': 1, 'H': 3, 'N': 2961, 'M': 3, 'D': 32, 'causal': False, 'mask': True, 'bias': False, 'bias_batch': False, 'single_kv': False, 'groups': 2, 'l2norm': True, 'scale': 8.0, 'seed': 254545501}" 2>&1 | grep -v amdgpu.ids | tee "$O/fuzz_model_probe.txt" ;;
+    ab_norm)   # finalize / l2norm variants: main = unrolled head loop + single-chunk l2norm on small grids; finold = round-5 code; finnt = nontemporal slab loads
+      ( timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,2048,128,1 --single-kv --groups 8 --scale 1 main finold finnt
+        timeout 300 python tools/ab_libs.py --rounds 4 --dtype f16 --shape 1,8,1024,64,0,8192,0,1:4,8,1024,64,0 main finold finnt
+        timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,4096,64,1 main finold ) 2>&1 | grep -v amdgpu.ids | tee "$O/ab_norm.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

@@ -6,20 +6,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import flash_cosine_sim_attention_amd as F
 from flash_cosine_sim_attention_amd import _lib
-B, H, N, D = 4, 8, 4096, 64
-q, k, v = (torch.randn(B, H, N, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+# SHAPE="B,H,N,D[,single_kv[,groups[,scale]]]" (default: C3); the trace arrays hold the first 256 workgroups of a launch
+_sh = [float(x) for x in os.environ.get("SHAPE", "4,8,4096,64").split(",")]
+B, H, N, D = (int(x) for x in _sh[:4])
+single, groups, scale = (len(_sh) > 4 and _sh[4] != 0), (int(_sh[5]) if len(_sh) > 5 else 1), (_sh[6] if len(_sh) > 6 else 8.0)
+q = torch.randn(B, H, N, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+k, v = (torch.randn((B, N, D) if single else (B, H, N, D), device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(2))
 do = torch.randn_like(q)
+print("shape", (B, H, N, D), "single_kv", single, "groups", groups, "scale", scale)
 for _ in range(int(os.environ.get("ITERS", "20"))):
     q.grad = k.grad = v.grad = None
-    F.flash_cosine_sim_attention(q, k, v, causal=True).backward(do)
+    F.flash_cosine_sim_attention(q, k, v, causal=True, groups=groups, scale=scale).backward(do)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (C.c_ulonglong * 2048)()
 for which in ("fwd", "dq", "dkv"):
-    fn = getattr(lib, "fcsa_trace_read_wg_" + which)
+    fn = getattr(lib, "fcsa_trace_read_wg_" + which, None)
+    if fn is None:
+        print(f"== {which}: no trace symbol in this build"); continue
     fn.argtypes = [C.POINTER(C.c_ulonglong)]
     assert fn(buf) == 0
-    n = 256
+    n = int(os.environ.get("NWG", "256"))
     st = [buf[2 * i] for i in range(n)]
     en = [buf[2 * i + 1] for i in range(n)]
     t0 = min(st)
