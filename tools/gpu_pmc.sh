@@ -3,6 +3,7 @@
 set -u
 export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/pmc"; mkdir -p "$O"
+export KERNEL_STATS_CSV="${KERNEL_STATS_CSV:-}"
 CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra-configs"
 run() { n=$1; shift; ( cd /tmp && timeout 300 rocprofv3 --pmc "$@" -d "$O/$n" -o p --output-format csv -- $CMD > "$O/$n.log" 2>&1 ); tail -n 2 "$O/$n.log" | cut -c1-200; }
 ( cd /tmp && rocprofv3 -L > "$O/counters_avail.txt" 2>&1 ); grep -c . "$O/counters_avail.txt"
