@@ -544,11 +544,11 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
         bool skip = false;
         if constexpr (MASKED) skip = causal && (j0 > mw + 31 + diff);
         const bool next_here = !last_of_stage;              // the next key tile sits in this stage's buffer
-        if (!skip) dq_tile_pipe<T, D, MODE>(kcur, vcur, next_here ? kcur + TILE_B : kcur, next_here ? vcur + TILE_B : vcur,
+        if (!skip) dq_tile_pipe<T, D, tile_mode<MODE>()>(kcur, vcur, next_here ? kcur + TILE_B : kcur, next_here ? vcur + TILE_B : vcur,
                                               next_here ? t + 1 : -1, t, fa, qf, dof, dq, lc, delta, word, ncm, i, j0, diff, pipe);
       } else if constexpr (MASKED) {
         const bool skip = causal && (j0 > mw + 31 + diff);
-        if (!skip) dq_tile<T, D, MODE, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
+        if (!skip) dq_tile<T, D, tile_mode<MODE>(), BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
       } else {
         dq_tile<T, D, 0, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, 0, ncm, i, j0, diff, bias_row, Mk);
       }
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
       }
       bool skip = t >= nt;
       if constexpr (MODE == 1) skip = skip || (causal && j0 > mw + 31 + diff);
-      if (!skip) dq_tile<T, D, MODE, BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
+      if (!skip) dq_tile<T, D, tile_mode<MODE>(), BIAS, TWO>(kcur, vcur, fa, qf, dof, dq, lc, delta, p, word, ncm, i, j0, diff, bias_row, Mk);
       if (more) dma_wait();
       FCSA_BAR_BEGIN(bar_t);
       __syncthreads();
@@ -1441,25 +1441,25 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
           if (!skip) {
             const bool has_next = t + 1 < QT;      // (else: the request reads this tile's buffer again and is never used)
             if constexpr (QSPLIT)
-              dkv_tile_pipe<T, D, BMS, MODE, true, true>(cur + hoff, cur + TILE_B + hoff, lcs + hq, dls + hq, fa, kf, vf, dk, dv, kmask, ncm, j, i0 + hq, diff, ts,
+              dkv_tile_pipe<T, D, BMS, tile_mode<MODE>(), true, true>(cur + hoff, cur + TILE_B + hoff, lcs + hq, dls + hq, fa, kf, vf, dk, dv, kmask, ncm, j, i0 + hq, diff, ts,
                                                           pipe, pipe_tile != t, has_next ? smem + par_nxt * BUF_B : cur, wave >= 4, hoff, hq);
             else
-            dkv_tile_pipe<T, D, BMQ, MODE, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, pipe_tile != t,
+            dkv_tile_pipe<T, D, BMQ, tile_mode<MODE>(), true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, pipe_tile != t,
                                                   has_next ? smem + par_nxt * BUF_B : cur, NW == 8 && wave >= 4);
             pipe_tile = has_next ? t + 1 : -1;
           }
           ring = par_nxt;
         } else {
-          if (!skip) dkv_tile_pipe<T, D, BMQ, MODE>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, true, nullptr,
+          if (!skip) dkv_tile_pipe<T, D, BMQ, tile_mode<MODE>()>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, kmask, ncm, j, i0, diff, ts, pipe, true, nullptr,
                                                     NW == 8 && wave >= 4);
         }
       } else if constexpr (LEAN) {
-        if (!skip) dkv_tile<T, D, BMQ, MODE, false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
+        if (!skip) dkv_tile<T, D, BMQ, tile_mode<MODE>(), false, true>(cur, cur + TILE_B, lcs, dls, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0, diff, nullptr, ts,
                                                             bb, bscr, nullptr, false, -1, lane, smem + LDS::VOWN, wave * 32, NW == 8 && wave >= 4);
       } else {
         const int next_i0 = more ? i0 + hq + BMQ : -1;      // (QSPLIT: of this wave's rows of the next staged tile)
         if (!skip) {
-          dkv_tile<T, D, BMS, MODE, BIAS>(cur + hoff, cur + TILE_B + hoff, lcs + hq, dls + hq, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0 + hq, diff, bias_col, ts, bb, bscr,
+          dkv_tile<T, D, BMS, tile_mode<MODE>(), BIAS>(cur + hoff, cur + TILE_B + hoff, lcs + hq, dls + hq, fa, kf, vf, dk, dv, p, kmask, ncm, j, i0 + hq, diff, bias_col, ts, bb, bscr,
                                             bias_blk, bvec, next_i0, lane);
         } else if constexpr (BIAS) {      // the block requested for this tile is not used: request the next tile's first block instead
           if (bvec && more) bb.request(bias_blk, min(next_i0 + (lane & 31), p.N - 1), (int64_t)p.M * TR::ES, fa.hi);

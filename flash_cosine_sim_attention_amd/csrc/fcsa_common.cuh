@@ -802,6 +802,15 @@ FCSA_DEV void mul16(f32x16& out, const f32x16& a, const f32x16& b) {
 }
 
 
+// Ablation build (-DFCSA_ABL_NOMASK; TIMING ONLY, results are wrong by construction): the tiles that need masking run the unmasked tile
+// body, with the tile loops, skips and barriers unchanged -- an upper bound on what ANY cheaper treatment of the causal diagonal / key
+// masks could gain (profiles/r06_ablations.txt).  Product builds: the identity.
+#ifdef FCSA_ABL_NOMASK
+template <int MODE> constexpr int tile_mode() { return 0; }
+#else
+template <int MODE> constexpr int tile_mode() { return MODE; }
+#endif
+
 // bit mask (over accumulator-row positions 0..31) of positions <= thr
 FCSA_DEV uint32_t le_mask(int thr) { return thr < 0 ? 0u : (thr >= 31 ? 0xffffffffu : ((2u << thr) - 1u)); }
 // bit mask of positions >= thr

@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         mid();
         if (PREFETCH_K && t + 1 < nt) request_k(knxt);
       } else {
-        fwd_tile<T, D, MODE, BIAS, LEAN, DYN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
+        fwd_tile<T, D, tile_mode<MODE>(), BIAS, LEAN, DYN>(vcur, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid, knxt, t + 1 < nt,
                                      vcur - SUB * TILE_B, BIAS_AHEAD ? &bnext : nullptr, bcur_ok, bfut_ok ? j0 + BN : -1);
         bnext_ok = bfut_ok;
       }
@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
         return;
       }
       if constexpr (!LEAN) request_k(buf + half * TILE_B);      // (bias form: the generic tile takes its K fragments from registers; nothing is prefetched across stages)
-      fwd_tile<T, D, MODE, BIAS, LEAN, DYN>(buf + (SUB + half) * TILE_B, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid,
+      fwd_tile<T, D, tile_mode<MODE>(), BIAS, LEAN, DYN>(buf + (SUB + half) * TILE_B, kf, fa, qf, o, l, lacc, p, c2row, rmax, word, ncm, i, j0, diff, bias_row, ts, mid,
                                            nullptr, false, buf + half * TILE_B);
     };
     for (int u = 0; u < u_split; ++u) stage(std::integral_constant<int, 0>{}, u);

@@ -43,6 +43,8 @@ for stage in "$@"; do
       ( timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,2048,128,1 --single-kv --groups 8 --scale 1 main finold finnt
         timeout 300 python tools/ab_libs.py --rounds 4 --dtype f16 --shape 1,8,1024,64,0,8192,0,1:4,8,1024,64,0 main finold finnt
         timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,4096,64,1 main finold ) 2>&1 | grep -v amdgpu.ids | tee "$O/ab_norm.txt" ;;
+    ablate)   # timing-only ablation: the masked (diagonal) tiles run the unmasked body (-DFCSA_ABL_NOMASK), DEV_ONLY builds of both arms
+      timeout 400 python tools/ab_libs.py --rounds 5 --shape 4,8,4096,64,1:4,8,2048,64,1 dev0 devnomask 2>&1 | grep -v amdgpu.ids | tee "$O/ablate_nomask.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
