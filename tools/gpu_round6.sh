@@ -45,6 +45,13 @@ for stage in "$@"; do
         timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,4096,64,1 main finold ) 2>&1 | grep -v amdgpu.ids | tee "$O/ab_norm.txt" ;;
     ablate)   # timing-only ablation: the masked (diagonal) tiles run the unmasked body (-DFCSA_ABL_NOMASK), DEV_ONLY builds of both arms
       timeout 400 python tools/ab_libs.py --rounds 5 --shape 4,8,4096,64,1:4,8,2048,64,1 dev0 devnomask 2>&1 | grep -v amdgpu.ids | tee "$O/ablate_nomask.txt" ;;
+    ab_ringsep)   # dK/dV ring form: 16-row epilogue scratch behind the ring + next pass requested from the epilogue (main) vs round 4's plan (nosep)
+      ( timeout 400 python tools/ab_libs.py --rounds 5 --shape 4,8,4096,64,1:4,8,2048,64,1:4,8,4096,64,0 main nosep
+        timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,2048,128,1 --single-kv --groups 8 --scale 1 main nosep
+        timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,4096,128,1:2,8,2048,96,1:2,8,2048,32,1 main nosep
+        timeout 300 python tools/ab_libs.py --rounds 4 --dtype f16 --shape 4,8,4096,64,1 main nosep ) 2>&1 | grep -v amdgpu.ids | tee "$O/ab_ring_sep.txt" ;;
+    parity_bwd)   # the backward-heavy parity files on the new library
+      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py tests/test_gpu_misc.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -n 4 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
