@@ -93,6 +93,17 @@ def event_time_ms(fn, iters=20, warm=10):
     return s.elapsed_time(e) / iters
 
 
+def protocol_time_ms(fn):
+    """The reference protocol (10 warm-ups, mean of 20 event-timed calls).  A 20-call window of a small configuration is 0.5 - 3 ms long --
+    shorter than the chip's clock ramp after the host-side pause in front of it, and the round-6 evidence session caught one such window at
+    5x its usual value -- so windows below 5 ms are measured five times (no further warm-up) and the MEDIAN window is reported."""
+    t = event_time_ms(fn)
+    if t * 20 < 5.0:
+        ts = sorted([t] + [event_time_ms(fn, warm=0) for _ in range(4)])
+        t = ts[len(ts) // 2]
+    return t
+
+
 def run_extra_config(F, c, sdpa=True):
     dt = _DT[c["dtype"]]
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -118,11 +129,11 @@ def run_extra_config(F, c, sdpa=True):
         F.flash_cosine_sim_attention(q, k, v, **kw).backward(do)
 
     r = {}
-    t_f = event_time_ms(fwd)
+    t_f = protocol_time_ms(fwd)
     r["fwd_ms"] = round(t_f, 4)
     r["fwd_tflops"] = round(4 * unit / t_f / 1e9, 1)
     if c["bwd"]:
-        t_fb = event_time_ms(fb)
+        t_fb = protocol_time_ms(fb)
         r["ms"] = round(t_fb, 4)
         r["tflops"] = round(14 * unit / t_fb / 1e9, 1)
     else:
@@ -143,7 +154,7 @@ def run_extra_config(F, c, sdpa=True):
                 q.grad = k.grad = v.grad = None
                 sd(q, ke, ve, attn_mask=am, is_causal=c["causal"]).backward(do)
 
-            ts = event_time_ms(sfb if c["bwd"] else sfwd)
+            ts = protocol_time_ms(sfb if c["bwd"] else sfwd)
             r["sdpa_ms"] = round(ts, 4)
             r["vs_flash_sdpa"] = round(ts / r["ms"], 2)
         except Exception as ex:                                   # pragma: no cover
@@ -367,9 +378,13 @@ def main():
                 if hit[2]:      # matrix-pipe occupancy and effective clock of the same PMC passes (tools/pmc_summary.py)
                     roofline["mfma_busy"] = hit[2].get("mfma_busy")
                     roofline["effective_clock_ghz"] = hit[2].get("effective_clock_ghz")
+                    if "mfma_busy_memtime" in hit[2]:      # the kernel's own clock (s_memtime, -DFCSA_TRACE_WG build; tools/pmc_clock_crosscheck.py)
+                        roofline["mfma_busy_memtime"] = hit[2]["mfma_busy_memtime"]
+                        roofline["effective_clock_ghz_memtime"] = hit[2]["effective_clock_ghz_memtime"]
                     roofline["mfma_busy_what"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE per XCD), effective clock = GRBM_GUI_ACTIVE "
                                                   "per XCD / kernel duration of the rocprofv3 kernel trace: the pipe's occupancy in REAL clocks next to `frac`, "
-                                                  "which prices the same launch against the 2.4 GHz nominal peak")
+                                                  "which prices the same launch against the 2.4 GHz nominal peak.  GRBM_GUI_ACTIVE of a profiled dispatch includes its set-up (the HBM-bound l2norm kernel "
+                                                  "reads 4.2 GHz that way): *_memtime uses the median workgroup duration in s_memtime ticks of the trace build instead")
             else:
                 roofline["traffic_source"] = ("null: no profiles/r*_pmc_traffic.json was measured on these kernel sources (source sha256 %s; "
                                               "library sha256 %s)" % (src[:12], lib_sha256()[:12]))

@@ -1,15 +1,16 @@
-"""Regenerates the measurement table of DESIGN.md section 6 (between the R05_TABLE markers) from the evidence files of a round:
-profiles/<tag>_bench_line.json, <tag>_pmc_traffic.json, <tag>_rocprofv3_kernel_stats.csv.   usage: python tools/design_table.py [r05]"""
+"""Regenerates the measurement table of DESIGN.md section 6 (between the MEASURED_TABLE markers) from the evidence files of a round:
+profiles/<tag>_bench_line.json, <tag>_pmc_traffic.json, <tag>_rocprofv3_kernel_stats.csv.   usage: python tools/design_table.py [r06]"""
 import csv
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = lambda n: os.path.join(ROOT, "profiles", f"{tag}_{n}")
 d = json.load(open(P("bench_line.json")))
-tr = json.load(open(P("pmc_traffic.json")))["kernels"]
+_pmc = json.load(open(P("pmc_traffic.json")))
+tr, derived = _pmc["kernels"], _pmc.get("derived", {})
 ks = {}
 for row in csv.DictReader(open(P("rocprofv3_kernel_stats.csv"))):
     n = row["Name"]
@@ -23,22 +24,25 @@ L = ["| what | value | source |", "|---|---|---|"]
 L.append(f"| **C3 step** (B4 H8 N4096 D64 bf16 causal, fwd + bwd) | **{d['ms_per_step']} ms = {d['value']:.1f} TFLOP/s** algorithmic, whole-step fraction of the 2.5 PFLOP/s MFMA peak **{r['whole_step']['frac']:.3f}**; {d['vs_flash_sdpa']:.2f}× `torch…SDPA` ({d['flash_sdpa']['ms_per_step']} ms) on the same box; reference protocol (`out.sum().backward()`, mean of 20) {d['reference_protocol']['ms']} ms | `profiles/{tag}_bench_line.json` |")
 L.append(f"| dominant kernel `bwd_dkv` | 137.47 GFLOP ÷ {r['avg_launch_us']} µs (instrumented pass; its kernels sum to {r['kernel_sum_per_step_us_instrumented']} µs per step vs {r['step_us_uninstrumented']} µs un-instrumented) = {r['achieved']} TFLOP/s = **{r['frac']:.3f}** of peak; scaled to the un-instrumented step {r['frac_scaled_to_step']:.3f}; rocprofv3 average {dkv_us:.2f} µs = {137.47e9 / (dkv_us * 1e-6) / 2.5e15:.3f} | bench line `roofline`; `profiles/{tag}_rocprofv3_kernel_stats.csv` |")
 L.append(f"| kernels per step (rocprofv3 `--kernel-trace --stats`) | `bwd_dkv` {ks.get('bwd_dkv_kernel', 0):.1f} µs, `bwd_dq` {ks.get('bwd_dq_kernel', 0):.1f}, `fwd` {ks.get('fwd_kernel', 0):.1f}, `l2norm` {ks.get('l2norm_kernel', 0):.1f}: {ksum:.1f} µs | `profiles/{tag}_rocprofv3_kernel_stats.csv` |")
+if derived:
+    cell = "; ".join(f"`{k.replace('_kernel', '')}` {v.get('mfma_busy', float('nan')):.3f} at {v.get('effective_clock_ghz', float('nan')):.2f} GHz" for k, v in derived.items() if "mfma_busy" in v and k != "l2norm_kernel")
+    L.append(f"| matrix-pipe occupancy in REAL clocks (`SQ_VALU_MFMA_BUSY_CYCLES` ÷ (4 SIMDs × 256 CUs × `GRBM_GUI_ACTIVE` per XCD)) and effective clock (`GRBM_GUI_ACTIVE` per XCD ÷ kernel-trace duration) | {cell} — the 2.5 PFLOP/s peak is quoted at 2.4 GHz | `profiles/{tag}_pmc_summary.txt`, bench line `roofline.mfma_busy` |")
 tot = sum(v["total_bytes"] for v in tr.values()) / 1e6
-L.append(f"| HBM traffic per launch (PMC, FETCH_SIZE×2 + WRITE_SIZE, tied to the library's sha256) vs algorithmic | l2norm {tr['l2norm_kernel']['total_bytes'] / 1e6:.1f} MB (33.5), fwd {tr['fwd_kernel']['total_bytes'] / 1e6:.1f} (84), dq {tr['bwd_dq_kernel']['total_bytes'] / 1e6:.1f} (101), dkv {tr['bwd_dkv_kernel']['total_bytes'] / 1e6:.1f} (101): {tot:.0f} MB per step vs SURVEY §8(d)'s 202 MB minimum (the saved c1·q̂ / k̂ and the dQ kernel's second read of K, V) at {tot / 1e6 / (d['ms_per_step'] * 1e-3):.1f} TB/s — not binding | `profiles/{tag}_pmc_traffic.json`, `{tag}_pmc_summary.txt` |")
+L.append(f"| HBM traffic per launch (PMC, FETCH_SIZE×2 + WRITE_SIZE, keyed on the hash of the kernel sources + Makefile) vs algorithmic | l2norm {tr['l2norm_kernel']['total_bytes'] / 1e6:.1f} MB (33.5), fwd {tr['fwd_kernel']['total_bytes'] / 1e6:.1f} (84), dq {tr['bwd_dq_kernel']['total_bytes'] / 1e6:.1f} (101), dkv {tr['bwd_dkv_kernel']['total_bytes'] / 1e6:.1f} (101): {tot:.0f} MB per step vs SURVEY §8(d)'s 202 MB minimum (the saved c1·q̂ / k̂ and the dQ kernel's second read of K, V) at {tot / 1e6 / (d['ms_per_step'] * 1e-3):.1f} TB/s — not binding | `profiles/{tag}_pmc_traffic.json`, `{tag}_pmc_summary.txt` |")
 L.append(f"| accuracy at C3 (rel-L2 vs float64 on the same bf16 inputs) | o {acc['hip']['o']['rel_l2']:.1e}, dq {acc['hip']['dq']['rel_l2']:.1e}, dk {acc['hip']['dk']['rel_l2']:.1e}, dv {acc['hip']['dv']['rel_l2']:.1e}; PyTorch composite in bf16: {acc['torch_same_dtype']['o']['rel_l2']:.1e} / {acc['torch_same_dtype']['dq']['rel_l2']:.1e} / {acc['torch_same_dtype']['dk']['rel_l2']:.1e} / {acc['torch_same_dtype']['dv']['rel_l2']:.1e} | bench line `accuracy` |")
 L.append(f"| C2 (B4 H8 N1024 D64 f16 fwd) | {c['C2']['fwd_ms']} ms, {c['C2']['fwd_tflops']} TFLOP/s, {c['C2']['vs_flash_sdpa']}× SDPA | bench line `configs` |")
 L.append(f"| C4 (cross-attention, key mask, f16) | fwd {c['C4']['fwd_ms']} ms, fwd + bwd {c['C4']['ms']} ms = {c['C4']['tflops']} TFLOP/s, {c['C4']['vs_flash_sdpa']}× SDPA | |")
 L.append(f"| C5 (single-head KV, groups 8, D128, scale 1 / scale 8) | {c['C5']['ms']} / {c['C5s8']['ms']} ms = {c['C5']['tflops']} / {c['C5s8']['tflops']} TFLOP/s; fwd {c['C5']['fwd_ms']} ms | |")
-L.append(f"| C3 at D = 128 | fwd {c['C3_d128']['fwd_ms']} ms = **{c['C3_d128']['fwd_tflops']} TFLOP/s** (k-l2norm launch + `fwd3_kernel`; round 4's driver record: 920), fwd + bwd {c['C3_d128']['ms']} ms = {c['C3_d128']['tflops']} TFLOP/s, {c['C3_d128']['vs_flash_sdpa']}× SDPA | |")
+L.append(f"| C3 at D = 128 | fwd {c['C3_d128']['fwd_ms']} ms = **{c['C3_d128']['fwd_tflops']} TFLOP/s** (k-l2norm launch + `fwd3_kernel`), fwd + bwd {c['C3_d128']['ms']} ms = {c['C3_d128']['tflops']} TFLOP/s, {c['C3_d128']['vs_flash_sdpa']}× SDPA | |")
 L.append(f"| C3 f16, scale 16 (online reference) | fwd {c['C3_f16_scale16']['fwd_ms']} ms, fwd + bwd {c['C3_f16_scale16']['ms']} ms = {c['C3_f16_scale16']['tflops']} TFLOP/s | |")
 L.append(f"| C2 + bias | {c['C2_bias']['ms']} ms | |")
 cb = d["cpu_baseline"]
 L.append(f"| CPU baseline (port of `plain_cosine_sim_attention` + autograd, 1 of 4 batch elements, {cb['cores']} host threads) | {cb['value']} TFLOP/s; tiled forward port {cb['tiled_forward']['value']}; C1 plain forward {cb['c1_plain_forward']['value']} | bench line `cpu_baseline` |")
-L.append(f"| head-dim × dtype sweep, benchmark.py tables, per-config kernel breakdown, host overhead | — | `profiles/{tag}_dims.txt`, `{tag}_benchmark_*.txt`, `{tag}_breakdown.txt`, `{tag}_host_overhead_*.txt` |")
+L.append(f"| head-dim × dtype sweep, benchmark.py tables, per-config kernel breakdown, host overhead | — | `profiles/{tag}_dims.txt`, `{tag}_benchmark_*.txt`, `{tag}_breakdown.txt` (event-pair regime), `{tag}_kstats.txt` (rocprofv3 kernel-trace durations of C5 / C2 / C4 / C3-D128), `{tag}_host_overhead_*.txt` |")
 table = "\n".join(L)
 fn = os.path.join(ROOT, "DESIGN.md")
 t = open(fn).read()
-b, e = "<!-- R05_TABLE_BEGIN -->", "<!-- R05_TABLE_END -->"
+b, e = "<!-- MEASURED_TABLE_BEGIN -->", "<!-- MEASURED_TABLE_END -->"
 assert b in t and e in t
 t = t[:t.index(b) + len(b)] + "\n" + table + "\n" + t[t.index(e):]
 open(fn, "w").write(t)

@@ -52,6 +52,12 @@ for stage in "$@"; do
         timeout 300 python tools/ab_libs.py --rounds 4 --dtype f16 --shape 4,8,4096,64,1 main nosep ) 2>&1 | grep -v amdgpu.ids | tee "$O/ab_ring_sep.txt" ;;
     parity_bwd)   # the backward-heavy parity files on the new library
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py tests/test_gpu_misc.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -n 4 ;;
+    fuzz_more)   # six more exploratory seeds (816 configurations) under the model-derived bars + the fwd3-vs-lean differential fuzz through the debug knob
+      for sd in 41 42 43 44 45 46; do
+        FCSA_FUZZ_SEED=$sd timeout 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -k random_config --maxfail=30 -p no:cacheprovider > "$O/fuzz_seed$sd.log" 2>&1
+        echo "FCSA_FUZZ_SEED=$sd: $(tail -n 1 "$O/fuzz_seed$sd.log")"; grep "AssertionError: {" "$O/fuzz_seed$sd.log" | cut -c1-500 | head -n 8
+      done | tee "$O/fuzz_more.txt"
+      timeout 900 python tools/fwd3_fuzz.py --n 300 --seed 7 2>&1 | grep -v amdgpu.ids | tail -n 6 | tee "$O/fwd3_fuzz.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
