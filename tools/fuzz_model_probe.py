@@ -34,14 +34,18 @@ for text in sys.argv[1:]:
         if c["mask"]:
             mask = torch.rand((B, M), device="cuda", generator=g) > 0.3
             mask[:, 0] = True
-        assert not c["bias"], "bias configurations: extend the probe"
+        bias = None
+        if c["bias"]:
+            bias = (0.5 * torch.randn((B if c["bias_batch"] else H, N, M), device="cuda", generator=g)).to(dt).requires_grad_()
         q.requires_grad_(); k.requires_grad_(); v.requires_grad_()
-        kw = dict(mask=mask, scale=c["scale"], groups=c["groups"], causal=c["causal"], l2norm_qk=c["l2norm"])
+        kw = dict(mask=mask, attn_bias=bias, scale=c["scale"], groups=c["groups"], causal=c["causal"], l2norm_qk=c["l2norm"],
+                  attn_bias_batch_dim=c["bias_batch"] if bias is not None else False)
         o = F.flash_cosine_sim_attention(q, k, v, **kw)
         do = torch.randn(o.shape, device="cuda", dtype=dt, generator=g)
         o.backward(do)
         torch.cuda.synchronize()
-        okw = dict(mask=None if mask is None else _npf(mask).astype(bool), scale=c["scale"], groups=c["groups"], causal=c["causal"], l2norm_qk=c["l2norm"])
+        okw = dict(mask=None if mask is None else _npf(mask).astype(bool), attn_bias=None if bias is None else _npf(bias), scale=c["scale"], groups=c["groups"],
+                   causal=c["causal"], l2norm_qk=c["l2norm"], attn_bias_batch_dim=kw["attn_bias_batch_dim"])
         args = (_npf(do), _npf(q), _npf(k), _npf(v))
         raw = O.attention_backward(*args, **okw)[:3]
         fai = O.attention_backward(*args, operand_dtype=dtype, o_saved=_npf(o), **okw)[:3] if dtype != "f32" else raw
