@@ -171,7 +171,9 @@ def evaluate(cfg, raw=True):
     # 6) DERIVES the allowance instead: the oracle evaluates the same problem with float32 accumulation and the kernels' rounding points
     # (`attention_backward_emulated`), and a gradient may be as far from float64 as max(stated bar, kModelSlack x that model's own error)
     # -- per gradient, so a dq or dv regression on a problem whose dk is ill-conditioned does not hide behind dk's allowance.  A kernel
-    # error beyond that is a defect by construction of the model, not conditioning.  (The model's backward is given the output the
+    # error beyond that is a defect by construction of the model, not conditioning.  The same rule applies LAZILY to every other problem:
+    # a gradient over its stated bar is held against the model before it fails (exploratory seeds 41 / 42 / 46: three tiny bf16 D = 16
+    # problems 1 - 12 % over the raw-input bar with the model at 0.7 - 1.0 of the kernel's error, profiles/r06_fuzz_model_probe_more.txt).  (The model's backward is given the output the
     # forward STORED, like the operand-faithful oracle: `o` is an input of the backward, and on a one-row problem the direction in which
     # single 16-bit elements of `o` were rounded decides dq / dk -- exploratory seed 31, L02: two correct implementations 3 - 5e-2 apart.)
     model_class = N <= 2 or (M <= 4 and N >= 64)
@@ -192,21 +194,26 @@ def evaluate(cfg, raw=True):
         names = ["dq", "dk", "dv"] + (["d_bias"] if bias is not None else [])
         gots = [_npf(q.grad)[sl_q], _npf(k.grad)[sl_k] if not cfg["single_kv"] else _npf(k.grad),
                 _npf(v.grad)[sl_k] if not cfg["single_kv"] else _npf(v.grad)] + ([_npf(bias.grad)] if bias is not None else [])
+        _model = []
+
+        def model():      # the working-precision model of this very problem (same inputs, same slices, the stored output), evaluated at most once
+            if not _model:
+                em = O.attention_backward_emulated(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, cfg["dtype"], o_saved=got,
+                                                   **{k_: v_ for k_, v_ in okw.items() if k_ != "eps"})
+                _model.append(dict(zip(names, em[1:])))
+            return _model[0]
+
         if cfg["dtype"] != "f32":
             # operand-faithful twin: exact arithmetic on the 16-bit operands, FIXED bars at every logit range
             ro, _ = O.attention_forward_stats(_npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], **okw)
             yield f"{pr}: forward excess (16-bit operands)", (np.abs(got - ro) - rtol * np.abs(ro)).max(), atol * max(vmax, 1.0)
             # (the backward's own input `o`: delta = rowsum(dO * o) is taken from the output the forward stored, oracle `o_saved`)
             grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, operand_dtype=cfg["dtype"], o_saved=got, **okw)
-            model = None
-            if model_class:      # the working-precision model of this very problem (same inputs, same slices)
-                em = O.attention_backward_emulated(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, cfg["dtype"], o_saved=got, **{k_: v_ for k_, v_ in okw.items() if k_ != "eps"})
-                model = dict(zip(names, em[1:]))
             for name, gg, rr in zip(names, gots, grads):
                 rel = _rel(gg, rr)
                 lim = GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
-                if model is not None:
-                    lim = max(lim, kModelSlack * _rel(model[name], rr))
+                if model_class or rel > lim:      # (lazily for the other problems: only an exceedance pays for the model)
+                    lim = max(lim, kModelSlack * _rel(model()[name], rr))
                 yield f"{pr}: {name} rel-L2 (16-bit operands)", rel, lim
         if not raw:
             continue
@@ -214,10 +221,6 @@ def evaluate(cfg, raw=True):
         excess = (np.abs(got - ro) - rtol * np.abs(ro)).max()
         yield f"{pr}: forward excess", excess, cond * atol * max(vmax, 1.0)
         grads = O.attention_backward(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, **okw)
-        model = None
-        if model_class:
-            em = O.attention_backward_emulated(_npf(do)[sl_q], _npf(q)[sl_q], kq, vq, cfg["dtype"], o_saved=got, **{k_: v_ for k_, v_ in okw.items() if k_ != "eps"})
-            model = dict(zip(names, em[1:]))
         for name, gg, rr in zip(names, gots, grads):
             # the floor keeps the ratio meaningful when the exact gradient is (nearly) zero.  f32 additionally gets an ABSOLUTE
             # allowance: where P == 1 (N = M = 1, or one unmasked key) dS == P (dP - delta) == 0 exactly and the kernel returns the f32
@@ -230,8 +233,8 @@ def evaluate(cfg, raw=True):
                 continue
             rel = err / max(np.linalg.norm(rr), floor)
             lim = cond * GRAD_TOL[cfg["dtype"]] * (1.5 if name == "d_bias" else 1.0)
-            if model is not None:
-                lim = max(lim, kModelSlack * np.linalg.norm(model[name] - rr) / max(np.linalg.norm(rr), floor))
+            if model_class or rel > lim:
+                lim = max(lim, kModelSlack * np.linalg.norm(model()[name] - rr) / max(np.linalg.norm(rr), floor))
             yield f"{pr}: {name} rel-L2", rel, lim
 
 

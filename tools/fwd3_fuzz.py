@@ -71,7 +71,10 @@ def run(cfg, seed):
     if not all(torch.isfinite(t).all() for t in new):
         bad.append("non-finite")
     d = (new[0].float() - old[0].float()).abs()
-    lim = 1.01 * ulp * old[0].float().abs() + 4 * ulp * 2.0 ** -7
+    # one ulp of the VALUE = ulp * |old|: between one and two spacings of the 16-bit grid (two at the top of a binade -- round 6, seed 7: one
+    # element of 7.4 M exactly two spacings apart at |old| = 0.957, 1.001 of the relative bar), so the bar is two spacings of |old|'s binade
+    spacing = torch.exp2(torch.floor(torch.log2(old[0].float().abs().clamp_min(2.0 ** -14)))) * ulp
+    lim = torch.maximum(1.01 * ulp * old[0].float().abs(), 2.0 * spacing) + 4 * ulp * 2.0 ** -7
     if not (d <= lim).all():
         w = (d / lim).argmax()      # the worst VIOLATOR (largest |new - old| relative to its own bar), not the largest difference
         bad.append("o: |new - old| %.3e at |old| %.3e (%.2f of the bar there; %d of %d elements over; largest difference %.3e)"

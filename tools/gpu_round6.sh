@@ -61,6 +61,8 @@ for stage in "$@"; do
     probe_more)   # the three marginal exceedances of exploratory seeds 41 / 42 / 46 (tiny bf16 D = 16 problems): kernel vs model
       ONE_DTYPE=1 timeout 300 python tools/fuzz_model_probe.py "{'id': 'c42', 'dtype': 'bf16', 'B': 2, 'H': 1, 'N': 5, 'M': 5, 'D': 16, 'causal': True, 'mask': False, 'bias': True, 'bias_batch': False, 'single_kv': False, 'groups': 2, 'l2norm': True, 'scale': 10.0, 'seed': 840320648}" "{'id': 'c46', 'dtype': 'bf16', 'B': 1, 'H': 1, 'N': 5, 'M': 178, 'D': 16, 'causal': True, 'mask': False, 'bias': False, 'bias_batch': False, 'single_kv': True, 'groups': 2, 'l2norm': True, 'scale': 8.0, 'seed': 158148712}" "{'id': 'L10', 'dtype': 'bf16', 'B': 1, 'H': 1, 'N': 130, 'M': 1449, 'D': 16, 'causal': True, 'mask': False, 'bias': False, 'bias_batch': True, 'single_kv': False, 'groups': 1, 'l2norm': True, 'scale': 16.0, 'seed': 592557245}" 2>&1 | grep -v amdgpu.ids | tee "$O/fuzz_model_probe_more.txt"
       timeout 600 python tools/fwd3_fuzz.py --n 300 --seed 7 --only 0 > /dev/null 2>&1; timeout 900 python tools/fwd3_fuzz.py --n 300 --seed 7 2>&1 | grep -v amdgpu.ids | tail -n 4 | tee "$O/fwd3_fuzz.txt" ;;
+    ab_rowsum)   # forward row sums: v_dot2c on the rounded pairs (product) vs plain adds of the un-rounded values vs none (timing only)
+      timeout 400 python tools/ab_libs.py --rounds 5 --shape 4,8,4096,64,1:4,8,4096,64,0 dev0 devrowadd devnorowsum 2>&1 | grep -v amdgpu.ids | tee "$O/ab_rowsum.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
