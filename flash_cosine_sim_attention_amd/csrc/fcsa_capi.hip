@@ -5,7 +5,11 @@
 // cu:1889) and every launch goes to the caller's stream (cf. the default-stream launches cu:1720).
 #include "../../include/fcsa.h"
 #include "fcsa_kernels.h"
+#ifdef FCSA_VAR_SPLIT_ENV
+#include "dev/fcsa_sweep_env.h"
+#endif
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -151,21 +155,76 @@ struct BwdLayout {
   int dkv_splits;         // > 1: split-query dK/dV kernel, dk_slab / dv_slab hold dkv_splits partial slabs each
 };
 
-// Split-key dQ: how many workgroups share one row tile's key range -- where the 128-row tiles cannot fill the chip (< 128
-// workgroups for 256 CUs; fcsa::cu_count()), the problem is not causal and every split keeps >= 512 keys.  Mirrors forward_splits: C4 (1 x 8 heads x
-// 1024 queries, 8192 keys) goes from 64 to 256 workgroups.  The ONE definition both the workspace size and the launch use.
-// Target: the split kernels are the 4-wave (128-row) forms; where those run two waves per SIMD (rows <= 128 bytes) a CU wants TWO
-// workgroups, i.e. 2 x CUs on the chip, else 1 x CUs.  (Round 2 aimed at 256 throughout: C4 ran its forward and dQ at half occupancy.)
+// ---- split counts (forward keys / dQ keys / dK-dV queries) -------------------------------------------------------------------------
+// Where a non-causal problem's 128-position tiles cannot fill the chip, several workgroups share one tile's loop range and write f32
+// partials that a second pass (fwd_combine_kernel / finalize) sums.  How many: rounds 2 - 5 took "enough workgroups for two per CU";
+// since round 6 the count is the argmin of a small cost model over s = 1 .. 16 (16-bit types; float32 keeps the old rule).  The model
+// prices, in microseconds on MI355X, what a launch with s splits costs:
+//   * the form the launchers run for that count: form A = the 8-wave one-workgroup-per-CU forms (forward: wave halves split the keys,
+//     fcsa_fwd.hip use_ksplit_fwd -- rows <= 128 bytes while tiles * s <= CUs, wider rows always; backward: whatever runs un-split),
+//     else 4-wave workgroups, one per CU (form B) or -- rows <= 128 bytes and more workgroups than CUs -- two per CU (form C);
+//   * a workgroup's time t0 + c * positions, t0 and c growing with D (the exponentials do not shrink with it: floor);
+//   * rounds of workgroups over the slots, a partly filled last round at alpha + (1 - alpha) * fill;
+//   * the second pass: a launch + s partial slabs read once.
+// Constants: least squares in log space over tools/split_sweep.py tables of 27 shapes x 7 counts per kernel, D = 16 .. 128
+// (profiles/r06_split_sweep_*.txt; tools/split_model_fit.py prints them and the table below).  Mean / worst regret of the model's choice
+// against the measured best: forward 0.9 / 10.9 %, dQ 0.3 / 4.5 %, dK/dV 0.2 / 3.6 %; the rule it replaces: 11.2 / 44 %, 8.9 / 42 %,
+// 11.8 / 52 % (it split 160 .. 224 tiles of a 2048-position problem three or four ways where the un-split 8-wave form is 30 - 50 %
+// faster, and took counts that leave a quarter-full last round).  The ONE definition both the workspace sizes and the launches use.
+struct SplitModel { double tA, cA, tB, cB, tC, cC, a0, b0, k0, k1, alpha; int slabs, extra; };
+static const SplitModel kSplitFwd = {5.57, 8.68, 3.61, 11.8, 5.77, 16.1, 0.0, 0.536, 7.77, 0.177, 0.585, 1, 1};
+static const SplitModel kSplitDq  = {11.3, 9.94, 2.35, 12.5, 1.0, 20.9, 0.369, 0.244, 12.2, 0.455, 0.526, 1, 0};
+static const SplitModel kSplitDkv = {11.5, 12.0, 2.25, 15.5, 1.0, 26.6, 0.11, 0.281, 13.5, 0.34, 0.528, 2, 0};
+// tiles: 128-position tiles the un-split grid has; rows: rows of ONE partial slab; len: positions the split loop runs over
+static double split_cost(const SplitModel& m, int D, int64_t tiles, int64_t rows, int len, int s, int cus, bool form_a) {
+  const bool wide = D * 2 > 128;
+  const double ft = m.a0 + (1.0 - m.a0) * D / 64.0, fc = m.b0 + (1.0 - m.b0) * std::max(0.44, D / 64.0);
+  const int64_t tot = tiles * s;
+  double t0 = m.tA, c = m.cA;
+  int64_t slots = cus;
+  if (!form_a) {
+    if (wide || tot <= cus) { t0 = m.tB; c = m.cB; }
+    else { t0 = m.tC; c = m.cC; slots = 2 * (int64_t)cus; }
+  }
+  const double per = t0 * ft + c * fc * ((double)len / s) / 1024.0;
+  const int64_t full = tot / slots, rem = tot % slots;
+  const double rounds = full == 0 ? 1.0 : (double)full + (rem == 0 ? 0.0 : m.alpha + (1.0 - m.alpha) * (double)rem / (double)slots);
+  const double second = s == 1 ? 0.0 : m.k0 + m.k1 * m.slabs * (double)s * (double)rows * (D + m.extra) * 4.0 / 1e6;
+  return rounds * per + second;
+}
+// fwd: the forward's form rule (see above); else the backward's (un-split = form A, split = 4-wave workgroups)
+static int best_split(const SplitModel& m, bool fwd, int D, int64_t tiles, int64_t rows, int len) {
+  const int cus = fcsa::cu_count();
+  if (tiles <= 0 || tiles >= cus) return 1;
+  int best = 1;
+  double best_cost = split_cost(m, D, tiles, rows, len, 1, cus, true);
+  for (int s = 2; s <= 16 && len / s >= 512; ++s) {
+    const bool form_a = fwd && (D * 2 > 128 || tiles * s <= cus);
+    const double cost = split_cost(m, D, tiles, rows, len, s, cus, form_a);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+// the rule of rounds 2 - 5, still used for float32: two 4-wave workgroups per CU where those run two waves per SIMD (rows <= 128 bytes)
 int split_target(const fcsa_problem& p) { return (elem_size(p.dtype) * p.dim_head <= 128 ? 2 : 1) * fcsa::cu_count(); }
-int backward_dq_splits(const fcsa_problem& p) {
-  if (p.causal) return 1;
-  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
+static int split_by_target(const fcsa_problem& p, int64_t wgs, int len) {
   const int target = split_target(p);
   if (wgs <= 0 || wgs >= target / 2) return 1;
   int64_t s = (target + wgs - 1) / wgs;
   if (s > 16) s = 16;
-  if (s > p.k_len / 512) s = p.k_len / 512;
+  if (s > len / 512) s = len / 512;
   return s >= 2 ? (int)s : 1;
+}
+
+// Split-key dQ: not causal, every split keeps >= 512 keys.  C4 (1 x 8 heads x 1024 queries, 8192 keys): 64 row tiles, 8 splits.
+int backward_dq_splits(const fcsa_problem& p) {
+  if (p.causal) return 1;
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/split_sweep.py, dev/fcsa_sweep_env.h): the count from the environment, per call
+  if (const int v = fcsa_dev::env_int("FCSA_DQ_SPLITS"); v >= 1) return std::min(std::min(v, 16), std::max(1, p.k_len / 64));
+#endif
+  const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
+  if (elem_size(p.dtype) == 2) return best_split(kSplitDq, false, p.dim_head, wgs, (int64_t)p.batch * p.heads * p.q_len, p.k_len);
+  return split_by_target(p, wgs, p.k_len);
 }
 
 // Split-query dK/dV: the mirror image -- few keys, many queries (B * H * ceil(M / 128) key tiles cannot fill the chip), not causal,
@@ -173,13 +232,12 @@ int backward_dq_splits(const fcsa_problem& p) {
 // slabs [batch * heads][split][M][D] and the finalize kernel sums them (and applies the l2norm backward to dK^).
 int backward_dkv_splits(const fcsa_problem& p) {
   if (p.causal || p.kv_heads != p.heads) return 1;
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only
+  if (const int v = fcsa_dev::env_int("FCSA_DKV_SPLITS"); v >= 1) return std::min(std::min(v, 16), std::max(1, p.q_len / 64));
+#endif
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.k_len + 127) / 128);
-  const int target = split_target(p);
-  if (wgs <= 0 || wgs >= target / 2) return 1;
-  int64_t s = (target + wgs - 1) / wgs;
-  if (s > 16) s = 16;
-  if (s > p.q_len / 512) s = p.q_len / 512;
-  return s >= 2 ? (int)s : 1;
+  if (elem_size(p.dtype) == 2) return best_split(kSplitDkv, false, p.dim_head, wgs, (int64_t)p.batch * p.heads * p.k_len, p.q_len);
+  return split_by_target(p, wgs, p.q_len);
 }
 
 int log2_blocks_per_group(const fcsa_problem& p) {     // log2(group size / 8), or -1 if not a power of two of 8-blocks
@@ -312,18 +370,18 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
   return timed("l2norm", "l2norm", s, [&] { return fcsa::launch_l2norm(dtype, np, s); });
 }
 
-// Split-key forward: how many workgroups share one row tile's key range.  Only where the 128-row tiles cannot fill the
-// chip (< 128 workgroups for 256 CUs; fcsa::cu_count()), the problem is not causal (key ranges of a causal row tile are short and uneven),
-// the static exponent shift applies (partials with a common shift add up exactly) and every split keeps >= 512 keys.
+// Split-key forward (the count: best_split above): only where the 128-row tiles cannot fill the chip, the problem is not causal (key
+// ranges of a causal row tile are short and uneven), the static exponent shift applies (partials with a common shift add up exactly)
+// and every split keeps >= 512 keys.
 static int forward_splits(const fcsa_problem& p) {
   if (p.causal || dynamic_shift(p, false)) return 1;      // (never called with a bias: fcsa_forward only splits bias-free problems)
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
-  const int target = split_target(p);
-  if (wgs <= 0 || wgs >= target / 2) return 1;
-  int64_t s = (target + wgs - 1) / wgs;
-  if (s > 16) s = 16;
-  if (s > p.k_len / 512) s = p.k_len / 512;
-  return s >= 2 ? (int)s : 1;
+  if (wgs <= 0) return 1;
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only
+  if (const int v = fcsa_dev::env_int("FCSA_SPLITS"); v >= 1) return std::min(std::min(v, 16), std::max(1, p.k_len / 64));
+#endif
+  if (elem_size(p.dtype) == 2) return best_split(kSplitFwd, true, p.dim_head, wgs, (int64_t)p.batch * p.heads * p.q_len, p.k_len);
+  return split_by_target(p, wgs, p.k_len);
 }
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }

@@ -42,6 +42,9 @@
 
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
+#ifdef FCSA_VAR_SPLIT_ENV
+#include "dev/fcsa_sweep_env.h"
+#endif
 
 namespace fcsa {
 // 64-key tiles per LDS stage of fwd_kernel where the stages arrive by LDS-DMA.  One: this kernel's barrier sits in the MIDDLE of a
@@ -1268,6 +1271,9 @@ template <typename T, int D>
 static bool use_ksplit_fwd(const FwdParams& p) {
   const int MT = (p.N + 127) / 128;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT) * (p.splits > 1 ? p.splits : 1);
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/split_sweep.py, dev/fcsa_sweep_env.h): FCSA_KSPLIT = 0 / 1 forces the form
+  if (const int v = fcsa_dev::env_int("FCSA_KSPLIT"); v >= 0) return v != 0;
+#endif
   if (D * Traits<T>::ES > 128) return true;
   return wgs <= cu_count();
 }

@@ -141,11 +141,12 @@ def test_backward_workspace_single_head_non_causal_stays_small(lib):
 
 def test_backward_workspace_split_query_dkv(lib):
     """Split-query dK/dV (few keys, many queries, not causal, K/V with heads): dkv_splits f32 slabs for dk and for dv, sized by the
-    rule the launch uses (fcsa_capi.hip backward_dkv_splits): batch * heads * ceil(M / 128) key tiles against 512 / 256 workgroups."""
+    rule the launch uses (fcsa_capi.hip backward_dkv_splits -> best_split: the argmin of the cost model over 1 .. 16)."""
     al = lambda x: (x + 255) // 256 * 256
-    # 1 x 8 heads x 1024 keys = 64 key tiles -> 8 splits of 1024 queries (its 512 dQ row tiles need no split)
+    # 1 x 8 heads x 1024 keys = 64 key tiles -> 4 splits of 2048 queries: 256 workgroups, one round (measured 53.3 us against 53.6 with
+    # the 8 splits of rounds 2 - 5, profiles/r06_split_sweep_bwd_d64.txt; its 512 dQ row tiles need no split)
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)
-    slab = 8 * 8 * 1024 * 64 * 4                                # splits x heads x M x D floats
+    slab = 4 * 8 * 1024 * 64 * 4                                # splits x heads x M x D floats
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 8192 * 4) + al(slab) + al(slab)
     # causal, single-headed K/V and key grids that fill the chip keep the unsplit kernel
     for kw in (dict(causal=1), dict(kv_heads=1)):
@@ -154,10 +155,49 @@ def test_backward_workspace_split_query_dkv(lib):
         assert lib.fcsa_backward_workspace_bytes(C.byref(q)) == al(8 * 8192 * 4) + 2 * al(single)
     p = _problem(batch=4, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)      # 256 key tiles
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(4 * 8 * 8192 * 4)
-    # 256-byte rows aim at one workgroup per CU: 2 heads x 4 key tiles = 8 -> 16 splits capped by 4096 / 512 = 8
+    # 2 heads x 4 key tiles of 256-byte rows = 8 workgroups: as many splits as keep 512 queries each (4096 / 512 = 8)
     p = _problem(batch=1, heads=2, kv_heads=2, q_len=4096, k_len=512, dim_head=128, dtype=2, l2norm_qk=1)
     slab = 8 * 2 * 512 * 128 * 4
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(2 * 4096 * 4) + al(slab) + al(slab)
+
+
+def _split_counts(lib, **kw):
+    """(forward, dQ, dK/dV) split counts of a 16-bit problem with fusable l2norm groups, read back from the workspace sizes"""
+    al = lambda x: (x + 255) // 256 * 256
+    p = _problem(l2norm_qk=1, **kw)
+    B, H, N, M, D = p.batch, p.heads, p.q_len, p.k_len, p.dim_head
+    fws, bws = lib.fcsa_forward_workspace_bytes(C.byref(p)), lib.fcsa_backward_workspace_bytes(C.byref(p))
+    f = [s for s in range(1, 17) if (0 if s == 1 else al(s * B * H * N * D * 4) + al(s * B * H * N * 4)) == fws]
+    b = [(sq, sk) for sq in range(1, 17) for sk in range(1, 17)
+         if al(B * H * N * 4) + (al(sq * B * H * N * D * 4) if sq > 1 else 0) + (2 * al(sk * B * H * M * D * 4) if sk > 1 else 0) == bws]
+    assert len(f) == 1 and len(b) == 1, (f, b)
+    return f[0], b[0][0], b[0][1]
+
+
+def test_split_counts_follow_the_measured_tables(lib):
+    """The split counts are the argmin of a cost model fitted to tools/split_sweep.py tables (fcsa_capi.hip best_split, round 6).  Pinned
+    here: its choice on shapes of those tables where the winner is clear (profiles/r06_split_sweep_*.txt; the CPU answer uses 256 CUs,
+    the MI355X count), and the invariants every count keeps."""
+    f16, bf16 = 1, 2
+    H8 = dict(batch=1, heads=8, kv_heads=8)
+    assert _split_counts(lib, dtype=f16, q_len=1024, k_len=8192, dim_head=64, **H8) == (4, 8, 1)          # C4: forward 33.3 us (8 splits: 34.8)
+    assert _split_counts(lib, dtype=f16, q_len=8192, k_len=1024, dim_head=64, **H8) == (1, 1, 4)          # its mirror image
+    # 192 row tiles of a 2048-key problem: the un-split 8-wave forms (25.7 / 30.8 us) -- rounds 2 - 5 split them three ways (37.0 / 43.6 us)
+    assert _split_counts(lib, dtype=f16, batch=3, heads=8, kv_heads=8, q_len=1024, k_len=2048, dim_head=64) == (1, 1, 1)
+    assert _split_counts(lib, dtype=f16, batch=3, heads=8, kv_heads=8, q_len=2048, k_len=1024, dim_head=64) == (1, 1, 1)
+    # 160 row tiles x 8192 keys: three splits = 480 workgroups in ONE round of two per CU (64.0 us; four splits leave a quarter-full
+    # second round: 78.5 us)
+    assert _split_counts(lib, dtype=f16, batch=1, heads=20, kv_heads=20, q_len=1024, k_len=8192, dim_head=64) == (3, 3, 1)
+    assert _split_counts(lib, dtype=bf16, q_len=512, k_len=4096, dim_head=128, **H8) == (8, 8, 1)         # 256-byte rows, 32 row tiles
+    assert _split_counts(lib, dtype=bf16, batch=2, heads=8, kv_heads=8, q_len=1024, k_len=2048, dim_head=128) == (2, 2, 1)
+    assert _split_counts(lib, dtype=f16, batch=1, heads=4, kv_heads=4, q_len=300, k_len=16384, dim_head=64) == (16, 16, 1)
+    # invariants: never causal, never when the tiles fill the chip, every split keeps >= 512 positions of its loop
+    assert _split_counts(lib, dtype=f16, q_len=1024, k_len=8192, dim_head=64, causal=1, **H8) == (1, 1, 1)
+    assert _split_counts(lib, dtype=f16, batch=4, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64) == (1, 1, 1)
+    for M in (511, 1023, 1024, 1500, 2047, 4096, 5000):
+        for tiles in (1, 7, 40, 100, 200):
+            f, dq, dkv = _split_counts(lib, dtype=bf16, batch=1, heads=tiles, kv_heads=tiles, q_len=128, k_len=M, dim_head=64)
+            assert 1 <= f <= 16 and 1 <= dq <= 16 and (f == 1 or M // f >= 512) and (dq == 1 or M // dq >= 512) and dkv == 1, (M, tiles, f, dq, dkv)
 
 
 def test_forward_needs_qn(lib):
@@ -185,8 +225,8 @@ def test_scale_range(lib):
 def test_forward_workspace_formula(lib):
     # split-key forward: only non-causal problems whose 128-row tiles cannot fill the chip, with >= 1024 keys
     al = lambda x: (x + 255) // 256 * 256
-    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64)      # C4: 64 row tiles -> 8 splits (512 workgroups)
-    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(8 * 8 * 1024 * 64 * 4) + al(8 * 8 * 1024 * 4)
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64)      # C4: 64 row tiles -> 4 splits (256 8-wave workgroups)
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(4 * 8 * 1024 * 64 * 4) + al(4 * 8 * 1024 * 4)
     p = _problem(batch=4, heads=8, kv_heads=8, q_len=1024, k_len=1024, dim_head=64)      # C2: 256 row tiles
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64, causal=1)

@@ -63,6 +63,10 @@ for stage in "$@"; do
       timeout 600 python tools/fwd3_fuzz.py --n 300 --seed 7 --only 0 > /dev/null 2>&1; timeout 900 python tools/fwd3_fuzz.py --n 300 --seed 7 2>&1 | grep -v amdgpu.ids | tail -n 4 | tee "$O/fwd3_fuzz.txt" ;;
     ab_rowsum)   # forward row sums: v_dot2c on the rounded pairs (product) vs plain adds of the un-rounded values vs none (timing only)
       timeout 400 python tools/ab_libs.py --rounds 5 --shape 4,8,4096,64,1:4,8,4096,64,0 dev0 devrowadd devnorowsum 2>&1 | grep -v amdgpu.ids | tee "$O/ab_rowsum.txt" ;;
+    ablate_x)   # timing only: dK/dV without the exponentials and products of its X phase -- how much of the one-wave-per-SIMD forms (C5, small D = 128 grids) is the X phase that no partner wave covers?  (the d*nox variants were a local edit of dkv_tile_pipe that was not kept; result: profiles/r06_ablate_x.txt)
+      ( timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,2048,128,1 --single-kv --groups 8 --scale 1 d128base d128nox
+        timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,4096,128,1:2,8,2048,128,1 d128base d128nox
+        timeout 300 python tools/ab_libs.py --rounds 4 --shape 4,8,4096,64,1 d64base d64nox ) 2>&1 | grep -v amdgpu.ids | tee "$O/ablate_x.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
