@@ -33,6 +33,9 @@
 
 #include "fcsa_common.cuh"
 #include "fcsa_kernels.h"
+#ifdef FCSA_VAR_SPLIT_ENV
+#include "dev/fcsa_sweep_env.h"
+#endif
 
 namespace fcsa {
 // Tuning constants (each settled by a same-box A/B on MI355X; the rejected alternatives are listed in DESIGN.md §8):
@@ -1614,9 +1617,17 @@ template <typename T, int D, bool BIAS> constexpr bool bwd_ksplit() {
 
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
-static int tile_waves(int64_t batch_heads, int len, bool causal) {
+static int tile_waves(int64_t batch_heads, int len, bool causal, bool narrow16 = false) {
   const int MT = (len + 255) / 256;
-  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8 ? 8 : 4;
+  if (batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8) return 8;
+  // 16-bit rows of <= 128 bytes (round 6, tools/form_sweep.py, profiles/r06_form_sweep_d64_b.txt): once the 128-position tiles outnumber
+  // the CUs -- where the split-halves 8-wave forms no longer apply -- the 256-position 8-wave workgroup beats two 4-wave workgroups per
+  // CU from 136 workgroups on 256 CUs up (dQ -3 ... -10 %, dK/dV -10 ... -20 %), not only from 7/8 of the CUs
+  if (narrow16) {
+    const int MT4 = (len + 127) / 128;
+    if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return 8;
+  }
+  return 4;
 }
 
 template <typename T, int D, bool BIAS, int NW, bool TWO, bool KSPLIT = false>
@@ -1652,8 +1663,16 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   constexpr bool NARROW = D * Traits<T>::ES <= kDq2WBytes;      // rows <= 128 bytes: two waves per SIMD whatever the grid
   if (p.dq_splits > 1) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);       // split-key path: 128-row tiles x key ranges (the key-split form measured level there)
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/form_sweep.py): FCSA_DQ_FORM = 1 row tiles of 8 waves, 2 key-split 8 waves, 3 four waves
+  if constexpr (NARROW && bwd_ksplit<T, D, BIAS>()) {
+    const int f = fcsa_dev::env_int("FCSA_DQ_FORM");
+    if (f == 1) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
+    if (f == 2) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
+    if (f == 3) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);
+  }
+#endif
   if constexpr (NARROW) {
-    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
+    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
     if constexpr (bwd_ksplit<T, D, false>()) {      // at most one 128-row workgroup per CU: its wave halves split the keys
       const int MT4 = (p.N + 127) / 128;
       if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= cu_count()) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
@@ -1711,8 +1730,16 @@ static hipError_t launch_dkv_nw(const BwdParams& p, hipStream_t s) {
 template <typename T, int D, bool BIAS>
 static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   if (p.dkv_splits > 1) return launch_dkv_nw<T, D, BIAS, 4>(p, s);       // split-query path: 128-key tiles x query ranges
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only: FCSA_DKV_FORM = 1 key tiles of 8 waves, 2 query-split 8 waves, 3 four waves
+  if constexpr (D * Traits<T>::ES <= kDkv2WBytes && bwd_ksplit<T, D, BIAS>() && (D == 64 || D == 32 || D == 16)) {
+    const int f = fcsa_dev::env_int("FCSA_DKV_FORM");
+    if (f == 1) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
+    if (f == 2) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);
+    if (f == 3) return launch_dkv_nw<T, D, BIAS, 4>(p, s);
+  }
+#endif
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
-    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
+    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal, Traits<T>::ES == 2) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
     if constexpr (bwd_ksplit<T, D, false>() && (D == 64 || D == 32 || D == 16)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
       const int KT4 = (p.M + 127) / 128;
       // (from 512 queries: below, the four or fewer 128-row tiles of a pass do not pay for the hand-over -- 23.5 vs 24.7 us at N = 333 / 777)

@@ -1224,19 +1224,22 @@ __global__ void __launch_bounds__(NW * 64, 1) fwd2_kernel(const FwdParams p) {
 #endif
 }
 
-// Wide or narrow forward kernel (measured on MI355X, bf16, B4 H8: tools/fwd_ab.py).  The wide kernel needs enough
-// 256-row workgroups to cover the 256 CUs.  It wins where the MFMA share of a tile is large or the sequence is long
-// (D = 32 / 64 non-causal: +3..22%; causal N = 8192: +5%; D = 96 against the ONE-wave narrow kernel of round 2: +25..34%);
-// with causal masking and short sequences its 256-row diagonal granularity costs more than the halved LDS traffic saves
-// (N = 4096: -6%, N = 1024: -20%).
+// Wide or narrow forward kernel (measured on MI355X, bf16, B4 H8: tools/fwd_ab.py, tools/form_sweep.py).  The wide kernel needs enough
+// 256-row workgroups to cover the 256 CUs.  Rounds 2 - 3 measured it ahead where the MFMA share of a tile is large or the sequence is
+// long (D = 32 / 64 non-causal: +3..22%; causal N = 8192: +5%; D = 96 against the ONE-wave narrow kernel of round 2: +25..34%); with
+// causal masking and short sequences its 256-row diagonal granularity costs more than the halved LDS traffic saves (N = 4096: -6%,
+// N = 1024: -20%).  Re-measured in round 6, after the 32-row kernel's round-4 gains: see use_wide_fwd.
 template <int D>
 static bool use_wide_fwd(const FwdParams& p) {
   const int MT = (p.N + 255) / 256;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
   if (wgs < 224) return false;
-  if (D == 96) return false;      // round 3: the lean two-waves-per-SIMD 32-row kernel beats it at D = 96 (-1 ... -6 %, profiles/r03_ab_d96_lean_vs_wide.txt)
-  if (!p.causal) return D >= 32;
-  return p.N >= 8192;
+  // Round 6 (tools/form_sweep.py, profiles/r06_form_sweep_*.txt): since round 4 (row sums on the VALU, LDS-DMA staging) the 32-row kernel
+  // at two waves per SIMD beats this one at D = 64 -- non-causal (4,8,4096) 135 vs 156 us, (8,8,2048) 74 vs 88, causal (4,8,8192) 273 vs
+  // 324 -- and at D = 16 (causal 8192: 155 vs 165); at D = 32 this kernel still wins on long key ranges (causal (4,8,8192) 183 vs 198,
+  // non-causal (2,8,8192) 172 vs 178; level at 2048 - 4096 keys, 7 % behind at 1024).  D = 96: the lean two-wave kernel (round 3).
+  if (D != 32) return false;
+  return p.causal ? p.N >= 8192 : p.M >= 4096;
 }
 
 template <typename T, int D>
@@ -1255,9 +1258,17 @@ static hipError_t launch_fwd2(const FwdParams& p, hipStream_t s) {
 // Waves per workgroup of the row-tile kernels: 8 (one 256-row workgroup per CU) when that still gives every CU a
 // workgroup, else 4 (two 128-row workgroups per CU).  Both keep two waves per SIMD; with 8 the K / V tiles are
 // staged once per CU instead of twice, i.e. half the global loads and LDS stores per wave (C3: forward -6%).
-static int row_tile_waves(int64_t batch_heads, int rows, bool causal) {
+static int row_tile_waves(int64_t batch_heads, int rows, bool causal, bool narrow16 = false) {
   const int MT = (rows + 255) / 256;
-  return batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8 ? 8 : 4;
+  if (batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8) return 8;
+  // 16-bit rows of <= 128 bytes (round 6, tools/form_sweep.py): once the 128-row tiles outnumber the CUs -- where the key-split 8-wave form
+  // no longer applies -- the 256-row 8-wave workgroup beats two 4-wave workgroups per CU from 136 workgroups on 256 CUs up
+  // (forward -5 ... -9 %, profiles/r06_form_sweep_d64_b.txt), not only from 7/8 of the CUs
+  if (narrow16) {
+    const int MT4 = (rows + 127) / 128;
+    if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return 8;
+  }
+  return 4;
 }
 
 // Key-split form (fwd_kernel<.., KSPLIT>): 128-row workgroups of 8 waves.  Where the 128-row four-wave workgroups would leave the SIMDs
@@ -1350,7 +1361,7 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   if (p.dyn) {                  // per-row exponent reference (online): the prefetching form, 8 waves where they fit two per SIMD
     if constexpr (D * Traits<T>::ES <= 128) {
-      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
+      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
     } else if constexpr (fwd_lean<T, D, BIAS>()) {
       if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true, true>(p, s);
     }
@@ -1365,8 +1376,16 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
     }
     return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
   }
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/form_sweep.py): FCSA_FWD_FORM = 1 row tiles of 8 waves, 2 key-split 8 waves, 3 four waves
+  if constexpr (D * Traits<T>::ES <= 128 && fwd_ksplit<T, D, BIAS>()) {
+    const int f = fcsa_dev::env_int("FCSA_FWD_FORM");
+    if (f == 1) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
+    if (f == 2) return launch_fwd_nw<T, D, BIAS, 8, false, !BIAS, true>(p, s);
+    if (f == 3) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
+  }
+#endif
   if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
-    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
+    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   } else if constexpr (fwd_lean<T, D, BIAS>()) {
     // the lean form needs its partner wave: one 8-wave workgroup per CU (a grid with two 4-wave workgroups per CU always has that)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
@@ -1379,7 +1398,15 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
 
 template <typename T, int D>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t s) {
-  if constexpr (Traits<T>::ES == 2 && D <= 64) {       // (D = 96 / 128 take the lean two-wave kernel, see use_wide_fwd)
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/form_sweep.py): FCSA_FWD_FORM = 4 the 64-rows-per-wave kernel, any other value > 0 never
+  if constexpr (Traits<T>::ES == 2 && D <= 64) {
+    if (const int f = fcsa_dev::env_int("FCSA_FWD_FORM"); f > 0) {
+      if (f == 4 && p.bias == nullptr && !p.dyn && p.splits <= 1 && p.mask == nullptr) return launch_fwd2<T, D>(p, s);
+      return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);
+    }
+  }
+#endif
+  if constexpr (Traits<T>::ES == 2 && D == 32) {       // (use_wide_fwd: the only head dim fwd2_kernel still wins at -- nothing else instantiates it)
     if (p.bias == nullptr && !p.dyn && p.splits <= 1 && p.mask == nullptr && use_wide_fwd<D>(p)) return launch_fwd2<T, D>(p, s);
   }
   return p.bias != nullptr ? launch_fwd_b<T, D, true>(p, s) : launch_fwd_b<T, D, false>(p, s);

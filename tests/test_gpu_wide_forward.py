@@ -1,9 +1,11 @@
 """Parity of the WIDE forward kernel (64 query rows per wave, rotating MFMA / softmax pipeline; fcsa_fwd.hip fwd2_kernel).
 
-launch_forward picks it when the 256-row workgroups cover the chip (>= 224 of them) and
-  * not causal and dim_head in (32, 64), or
-  * causal and dim_head <= 64 and N >= 8192
-(dim_head 96 went to the lean two-wave 32-row kernel in round 3; its cases below stay as parity cases of that kernel).
+launch_forward picks it when the 256-row workgroups cover the chip (>= 224 of them), dim_head is 32 and
+  * not causal with >= 4096 keys, or
+  * causal with N >= 8192
+(rounds 1 - 5 also sent dim_head 64 and non-causal problems of any length there; round 6 re-measured: the 32-row kernel at two waves
+per SIMD is 13 - 16 % faster at dim_head 64 since its round-4 changes -- fcsa_fwd.hip use_wide_fwd.  dim_head 96 went to the lean
+two-wave 32-row kernel in round 3.  The other cases below stay as parity cases of whatever kernel the dispatch gives them).
 The shapes below are chosen to land on it through the normal dispatch:
   * many small heads (batch*heads = 224+), checked against the float64 oracle elementwise with the stated tolerances,
   * the long causal shapes, checked on (batch, head) slices against a float32 PyTorch evaluation on the GPU
@@ -45,6 +47,8 @@ WIDE_SMALL = [
     (4, 60, 320, 129, 96, torch.bfloat16, True, 3, 6),      # tail key tile of 1 key
     (14, 16, 512, 512, 64, torch.float16, False, 1, 16),    # larger scale
     (5, 48, 270, 70, 32, torch.float16, True, 1, 8),
+    (8, 28, 300, 4170, 32, torch.float16, False, 1, 8),     # the wide kernel's non-causal regime since round 6: >= 4096 keys, ragged tail
+    (8, 28, 257, 4096, 32, torch.bfloat16, False, 4, 2),    # ... grouped l2norm, N just past one 256-row tile
 ]
 
 
