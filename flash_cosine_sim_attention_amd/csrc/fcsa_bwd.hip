@@ -1617,13 +1617,14 @@ template <typename T, int D, bool BIAS> constexpr bool bwd_ksplit() {
 
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
-static int tile_waves(int64_t batch_heads, int len, bool causal, bool narrow16 = false) {
+static int tile_waves(int64_t batch_heads, int len, bool causal, bool bits16 = false) {
   const int MT = (len + 255) / 256;
   if (batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8) return 8;
-  // 16-bit rows of <= 128 bytes (round 6, tools/form_sweep.py, profiles/r06_form_sweep_d64_b.txt): once the 128-position tiles outnumber
-  // the CUs -- where the split-halves 8-wave forms no longer apply -- the 256-position 8-wave workgroup beats two 4-wave workgroups per
-  // CU from 136 workgroups on 256 CUs up (dQ -3 ... -10 %, dK/dV -10 ... -20 %), not only from 7/8 of the CUs
-  if (narrow16) {
+  // 16-bit types (round 6, tools/form_sweep.py): once the 128-position tiles outnumber the CUs -- where the split-halves 8-wave forms no
+  // longer apply -- the 256-position 8-wave workgroup wins from 132 workgroups on 256 CUs up, not only from 7/8 of the CUs: rows <= 128
+  // bytes dQ -3 ... -10 %, dK/dV -10 ... -20 % (profiles/r06_form_sweep_d64_b.txt); D = 96 / 128 lean dK/dV -15 ... -20 %
+  // (profiles/r06_form_sweep_d128_b.txt)
+  if (bits16) {
     const int MT4 = (len + 127) / 128;
     if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return 8;
   }
@@ -1669,6 +1670,11 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
     if (f == 1) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
     if (f == 2) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
     if (f == 3) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);
+  } else if constexpr (!NARROW && dq_can_two_waves<T, D>() && !BIAS && bwd_ksplit<T, D, BIAS>()) {      // 16-bit D = 96 / 128: 1 = four waves, two-wave tile, 2 = key-split 8 waves (causal), 3 = four waves, one per SIMD
+    const int f = fcsa_dev::env_int("FCSA_DQ_FORM");
+    if (f == 1) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
+    if (f == 2 && p.causal) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
+    if (f == 3) return launch_dq_nw<T, D, BIAS, 4, NARROW>(p, s);
   }
 #endif
   if constexpr (NARROW) {
@@ -1681,7 +1687,9 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
     // two waves per SIMD need two 128-row workgroups on every CU; smaller grids keep the one-wave (pipelined) form
     // (bias launches keep the one-wave form too: their two-wave instantiation spills 17 registers and was never measured ahead)
     const int MT4 = (p.N + 127) / 128;
-    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) >= cu_count() * 7 / 4) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
+    // (round 6: from MORE 128-row workgroups than CUs on -- rounds 3 - 5 asked for 7/4 of the CUs; at 264 ... 416 workgroups on 256 CUs the two-wave
+    //  tile is 19 - 28 % faster than the one-wave and key-split forms: profiles/r06_form_sweep_d128_b.txt)
+    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return launch_dq_nw<T, D, BIAS, 4, true>(p, s);
     // fewer: the same tile, 8 waves on 128 rows.  Causal launches only: 256-byte rows have no non-causal instantiation of the two-wave tile
     // (GENERAL_ONLY in launch_dq_nw), and the general one measured +6 % there against the one-wave pipelined form
     if constexpr (bwd_ksplit<T, D, BIAS>()) {
@@ -1736,6 +1744,10 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
     if (f == 1) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
     if (f == 2) return launch_dkv_nw<T, D, BIAS, 8, false, true>(p, s);
     if (f == 3) return launch_dkv_nw<T, D, BIAS, 4>(p, s);
+  } else if constexpr (Traits<T>::ES == 2 && !BIAS && D * Traits<T>::ES > kDkv2WBytes && D * Traits<T>::ES <= 256) {      // 16-bit D = 96 / 128: 1 = lean 8 waves, 3 = four waves (pipelined, one per SIMD)
+    const int f = fcsa_dev::env_int("FCSA_DKV_FORM");
+    if (f == 1) return launch_dkv_nw<T, D, BIAS, 8, true>(p, s);
+    if (f == 3) return launch_dkv_nw<T, D, BIAS, 4>(p, s);
   }
 #endif
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
@@ -1749,7 +1761,7 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
     // lean form (two waves per SIMD, V fragments from the LDS) where an 8-wave workgroup per CU still covers the chip; smaller grids
     // keep the one-wave pipelined form.  (Two 4-wave workgroups per CU would do as well, but a grid with >= 448 of those always has
     // >= 224 of the 8-wave ones.)
-    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal) == 8) return launch_dkv_nw<T, D, BIAS, 8, true>(p, s);
+    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal, true) == 8) return launch_dkv_nw<T, D, BIAS, 8, true>(p, s);
   }
   return launch_dkv_nw<T, D, BIAS, 4>(p, s);
 }

@@ -1258,13 +1258,14 @@ static hipError_t launch_fwd2(const FwdParams& p, hipStream_t s) {
 // Waves per workgroup of the row-tile kernels: 8 (one 256-row workgroup per CU) when that still gives every CU a
 // workgroup, else 4 (two 128-row workgroups per CU).  Both keep two waves per SIMD; with 8 the K / V tiles are
 // staged once per CU instead of twice, i.e. half the global loads and LDS stores per wave (C3: forward -6%).
-static int row_tile_waves(int64_t batch_heads, int rows, bool causal, bool narrow16 = false) {
+static int row_tile_waves(int64_t batch_heads, int rows, bool causal, bool bits16 = false) {
   const int MT = (rows + 255) / 256;
   if (batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8) return 8;
-  // 16-bit rows of <= 128 bytes (round 6, tools/form_sweep.py): once the 128-row tiles outnumber the CUs -- where the key-split 8-wave form
-  // no longer applies -- the 256-row 8-wave workgroup beats two 4-wave workgroups per CU from 136 workgroups on 256 CUs up
-  // (forward -5 ... -9 %, profiles/r06_form_sweep_d64_b.txt), not only from 7/8 of the CUs
-  if (narrow16) {
+  // 16-bit types (round 6, tools/form_sweep.py): once the 128-row tiles outnumber the CUs -- where the key-split 8-wave form would need a
+  // second round of workgroups -- the 256-row 8-wave workgroup wins from 132 workgroups on 256 CUs up, not only from 7/8 of the CUs:
+  // rows <= 128 bytes against two 4-wave workgroups per CU -5 ... -9 % (profiles/r06_form_sweep_d64_b.txt), D = 96 / 128 (lean form)
+  // against the key-split form -25 ... -35 % (profiles/r06_form_sweep_d128_b.txt)
+  if (bits16) {
     const int MT4 = (rows + 127) / 128;
     if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return 8;
   }
@@ -1363,7 +1364,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
     if constexpr (D * Traits<T>::ES <= 128) {
       if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
     } else if constexpr (fwd_lean<T, D, BIAS>()) {
-      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, true, true>(p, s);
+      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, true) == 8) return launch_fwd_nw<T, D, BIAS, 8, true, true>(p, s);
     }
     if constexpr (fwd_ksplit<T, D, BIAS>()) {
       if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, true, !BIAS, true>(p, s);
@@ -1382,13 +1383,18 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
     if (f == 1) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
     if (f == 2) return launch_fwd_nw<T, D, BIAS, 8, false, !BIAS, true>(p, s);
     if (f == 3) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
+  } else if constexpr (fwd_lean<T, D, BIAS>() && fwd_ksplit<T, D, BIAS>()) {      // 16-bit D = 96 / 128: 1 = lean 256-row tiles, 2 = lean key-split, 3 = four waves (one per SIMD)
+    const int f = fcsa_dev::env_int("FCSA_FWD_FORM");
+    if (f == 1) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
+    if (f == 2) return launch_fwd_nw<T, D, BIAS, 8, false, !BIAS, true>(p, s);
+    if (f == 3) return launch_fwd_nw<T, D, BIAS, 4, false>(p, s);
   }
 #endif
   if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   } else if constexpr (fwd_lean<T, D, BIAS>()) {
     // the lean form needs its partner wave: one 8-wave workgroup per CU (a grid with two 4-wave workgroups per CU always has that)
-    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
+    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, true) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
   }
   if constexpr (fwd_ksplit<T, D, BIAS>()) {
     if (use_ksplit_fwd<T, D>(p)) return launch_fwd_nw<T, D, BIAS, 8, false, !BIAS, true>(p, s);
@@ -1434,6 +1440,11 @@ static hipError_t launch_fwd_d(int D, const FwdParams& p, hipStream_t s) {
 
 hipError_t launch_forward(int dtype, int D, const FwdParams& p, hipStream_t s) {
   if (p.B * p.H == 0 || p.N == 0) return hipSuccess;
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only: FCSA_FWD_FORM = 5 forces the D = 128 64-rows-per-wave kernel whatever the grid, 1 .. 4 never take it
+  if (const int f = fcsa_dev::env_int("FCSA_FWD_FORM"); f > 0) {
+    if (f == 5 && D == 128 && (dtype == 1 || dtype == 2) && p.bias == nullptr && p.mask == nullptr && !p.dyn && p.splits <= 1) return launch_forward_wide128(dtype, p, s);
+  } else
+#endif
   if (use_forward_wide128(dtype, D, p)) return launch_forward_wide128(dtype, p, s);
   if (dtype == 2) return launch_fwd_d<BF16>(D, p, s);
   if (dtype == 1) return launch_fwd_d<F16>(D, p, s);

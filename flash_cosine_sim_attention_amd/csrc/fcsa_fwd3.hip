@@ -592,14 +592,20 @@ int forward_wide128_mode(int set) {      // set < 0: query only; returns the pre
 }
 
 // Does this problem take the form above?  16-bit D = 128, static exponent shift, no bias, no key mask, no key split, a grid of 256-row
-// (causal: paired) workgroups that covers the chip, K / V slices addressable with 32-bit offsets.
+// (causal: paired) workgroups that covers the chip -- or, from 2048 keys, more than half of it -- K / V slices addressable with 32-bit offsets.
 bool use_forward_wide128(int dtype, int D, const FwdParams& p) {
   if (D != 128 || (dtype != 1 && dtype != 2)) return false;
   if (p.bias != nullptr || p.mask != nullptr || p.dyn || p.splits > 1) return false;
   if (g_wide128.load(std::memory_order_relaxed) == 0) return false;
   const int MT = (p.N + 255) / 256;
   const int64_t wgs = (int64_t)p.B * p.H * (p.causal ? (MT + 1) / 2 : MT);
-  if (wgs < cu_count() * 7 / 8) return false;
+  if (wgs < cu_count() * 7 / 8) {
+    // round 6 (tools/form_sweep.py, profiles/r06_form_sweep_d128_b.txt): also where the 128-row tiles outnumber the CUs (132 ... 223 of
+    // these workgroups on 256 CUs) and the pass is long enough for its prologue: 31 - 36 % faster than the key-split lean form there, and
+    // ahead of the 256-row lean form from 2048 keys (level at 1024 keys up to ~176 workgroups, behind beyond)
+    const int MT4 = (p.N + 127) / 128;
+    if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= cu_count() || p.M < 2048) return false;
+  }
   if ((int64_t)(p.M + 64 * 6) * p.k.sn >= 0x7fffffffLL || (int64_t)(p.M + 64 * 6) * p.v.sn >= 0x7fffffffLL) return false;
   if ((int64_t)(p.N + 256) * p.q.sn >= 0x7fffffffLL) return false;
   return true;

@@ -26,11 +26,13 @@ def _npf(t):
     return t.detach().cpu().double().numpy()
 
 
-def _grid_ok(B, H, N, causal):
-    """the dispatch rule of use_forward_wide128 (csrc/fcsa_fwd3.hip): 256-row (causal: paired) workgroups >= 7/8 of the device's CUs"""
-    MT = (N + 255) // 256
+def _grid_ok(B, H, N, causal, M=0):
+    """the dispatch rule of use_forward_wide128 (csrc/fcsa_fwd3.hip): 256-row (causal: paired) workgroups >= 7/8 of the device's CUs, or
+    -- round 6 -- more 128-row tiles than CUs and >= 2048 keys"""
+    MT, MT4 = (N + 255) // 256, (N + 127) // 128
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    return B * H * ((MT + 1) // 2 if causal else MT) >= cus * 7 // 8
+    if B * H * ((MT + 1) // 2 if causal else MT) >= cus * 7 // 8: return True
+    return B * H * ((MT4 + 1) // 2 if causal else MT4) > cus and M >= 2048
 
 
 CASES = [
@@ -52,6 +54,8 @@ CASES = [
     ("full_no_l2norm",         15, 16, 300, 300,  torch.bfloat16, False,  1, 0.125, False, False),   # the reference extension's contract: q, k as given
     ("causal_scale_m8",        8, 28, 260,  260,  torch.bfloat16, True,   1, -8.0, False, True),
     ("ring_wraps_twice",       15, 16, 256, 460,  torch.bfloat16, False,  1, 8.0, False, True),      # 8 tiles: every ring slot is refilled twice
+    ("half_grid_causal",       4, 10, 2048, 2048, torch.bfloat16, True,   1, 8.0, False, True),      # 160 paired workgroups on 256 CUs (round 6's range)
+    ("half_grid_full_ragged",  1, 36, 1000, 2100, torch.float16,  False,  1, 8.0, False, True),      # 144 workgroups, ragged rows and keys
 ]
 
 
@@ -60,7 +64,7 @@ def test_wide128_matches_oracle(case):
     import flash_cosine_sim_attention_amd as F
     from oracle import cosine_sim_oracle as O
     name, B, H, N, M, dtype, causal, groups, scale, single, l2norm = case
-    assert _grid_ok(B, H, N, causal), "shape would not dispatch to the wide D = 128 forward"
+    assert _grid_ok(B, H, N, causal, M), "shape would not dispatch to the wide D = 128 forward"
     D = 128
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + N + M)
     q = torch.randn((B, H, N, D), device="cuda", dtype=dtype, generator=g)
