@@ -1617,16 +1617,29 @@ template <typename T, int D, bool BIAS> constexpr bool bwd_ksplit() {
 
 // ---------------------------------------------------------------------------------------------
 // 8 waves per workgroup when the grid still gives every CU a workgroup (see row_tile_waves in fcsa_fwd.hip), else 4
-static int tile_waves(int64_t batch_heads, int len, bool causal, bool bits16 = false) {
-  const int MT = (len + 255) / 256;
-  if (batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8) return 8;
+// tail: the last-round rule (below): 1 = dK/dV (and the forward, fcsa_fwd.hip row_tile_waves), 2 = dQ
+static int tile_waves(int64_t batch_heads, int len, bool causal, bool bits16 = false, int tail = 0) {
+  const int MT = (len + 255) / 256, cus = cu_count();
+  const int64_t w256 = batch_heads * (causal ? (MT + 1) / 2 : MT);
+  // More 256-position workgroups than CUs, 16-bit (round 6, profiles/r06_form_sweep_big*.txt): the LAST round decides.  A last round that
+  // fills at most ~55 % of the CUs costs the 8-wave form a whole 256-position workgroup time; as 4-wave workgroups the same tail is
+  // 128-position workgroups running alone on their CUs: dK/dV -5 ... -9 % at 264 ... 384, 544 ... 640, 800, 1088 workgroups on 256 CUs
+  // (D = 128 lean form against the pipelined 4-wave form: -8 ... -12 % at 264 ... 352), full or nearly full last rounds keep the 8-wave
+  // form.  dQ: the 4-wave form wins whenever the last round is not full (-3 ... -25 %); with whole rounds the 8-wave form is ahead (C3,
+  // one round: 6 %; (8,8,4096,64) causal, two rounds: 4 %, profiles/r06_ab_forms_tail.txt).
+  if (bits16 && tail != 0 && w256 > cus) {
+    const int64_t rem = w256 % cus;
+    if (tail == 2) return rem != 0 ? 4 : 8;
+    return (rem != 0 && rem * 20 <= (int64_t)cus * 11) ? 4 : 8;
+  }
+  if (w256 >= cus * 7 / 8) return 8;
   // 16-bit types (round 6, tools/form_sweep.py): once the 128-position tiles outnumber the CUs -- where the split-halves 8-wave forms no
   // longer apply -- the 256-position 8-wave workgroup wins from 132 workgroups on 256 CUs up, not only from 7/8 of the CUs: rows <= 128
   // bytes dQ -3 ... -10 %, dK/dV -10 ... -20 % (profiles/r06_form_sweep_d64_b.txt); D = 96 / 128 lean dK/dV -15 ... -20 %
   // (profiles/r06_form_sweep_d128_b.txt)
   if (bits16) {
     const int MT4 = (len + 127) / 128;
-    if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return 8;
+    if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cus) return 8;
   }
   return 4;
 }
@@ -1678,7 +1691,7 @@ static hipError_t launch_dq_b(const BwdParams& p, hipStream_t s) {
   }
 #endif
   if constexpr (NARROW) {
-    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
+    if (tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2, 2) == 8) return launch_dq_nw<T, D, BIAS, 8, true>(p, s);
     if constexpr (bwd_ksplit<T, D, false>()) {      // at most one 128-row workgroup per CU: its wave halves split the keys
       const int MT4 = (p.N + 127) / 128;
       if ((int64_t)p.B * p.H * (p.causal ? (MT4 + 1) / 2 : MT4) <= cu_count()) return launch_dq_nw<T, D, BIAS, 8, true, true>(p, s);
@@ -1751,7 +1764,7 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
   }
 #endif
   if constexpr (D * Traits<T>::ES <= kDkv2WBytes) {
-    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal, Traits<T>::ES == 2) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
+    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal, Traits<T>::ES == 2, 1) == 8) return launch_dkv_nw<T, D, BIAS, 8>(p, s);
     if constexpr (bwd_ksplit<T, D, false>() && (D == 64 || D == 32 || D == 16)) {      // at most one 128-key workgroup per CU: its wave halves split the queries
       const int KT4 = (p.M + 127) / 128;
       // (from 512 queries: below, the four or fewer 128-row tiles of a pass do not pay for the hand-over -- 23.5 vs 24.7 us at N = 333 / 777)
@@ -1761,7 +1774,7 @@ static hipError_t launch_dkv_b(const BwdParams& p, hipStream_t s) {
     // lean form (two waves per SIMD, V fragments from the LDS) where an 8-wave workgroup per CU still covers the chip; smaller grids
     // keep the one-wave pipelined form.  (Two 4-wave workgroups per CU would do as well, but a grid with >= 448 of those always has
     // >= 224 of the 8-wave ones.)
-    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal, true) == 8) return launch_dkv_nw<T, D, BIAS, 8, true>(p, s);
+    if (tile_waves((int64_t)p.B * p.H, p.M, p.causal, true, 1) == 8) return launch_dkv_nw<T, D, BIAS, 8, true>(p, s);
   }
   return launch_dkv_nw<T, D, BIAS, 4>(p, s);
 }

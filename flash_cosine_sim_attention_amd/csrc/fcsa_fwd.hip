@@ -1258,16 +1258,26 @@ static hipError_t launch_fwd2(const FwdParams& p, hipStream_t s) {
 // Waves per workgroup of the row-tile kernels: 8 (one 256-row workgroup per CU) when that still gives every CU a
 // workgroup, else 4 (two 128-row workgroups per CU).  Both keep two waves per SIMD; with 8 the K / V tiles are
 // staged once per CU instead of twice, i.e. half the global loads and LDS stores per wave (C3: forward -6%).
-static int row_tile_waves(int64_t batch_heads, int rows, bool causal, bool bits16 = false) {
-  const int MT = (rows + 255) / 256;
-  if (batch_heads * (causal ? (MT + 1) / 2 : MT) >= cu_count() * 7 / 8) return 8;
+// tail: also apply the last-round rule of rows <= 128 bytes (below)
+static int row_tile_waves(int64_t batch_heads, int rows, bool causal, bool bits16 = false, bool tail = false) {
+  const int MT = (rows + 255) / 256, cus = cu_count();
+  const int64_t w256 = batch_heads * (causal ? (MT + 1) / 2 : MT);
+  // More 256-row workgroups than CUs, 16-bit rows <= 128 bytes (round 6, profiles/r06_form_sweep_big*.txt): the LAST round decides.  A
+  // last round that fills at most ~55 % of the CUs costs the 8-wave form a whole 256-row workgroup time; as 4-wave workgroups (two per
+  // CU) the same tail is 128-row workgroups running alone on their CUs: 264 ... 384 and 544 ... 640 workgroups on 256 CUs -4 ... -11 %,
+  // 800 and 1088 -6 ... -8 %.  Full or nearly full last rounds (C3: exactly 256) keep the 8-wave form (K / V staged once per CU).
+  if (bits16 && tail && w256 > cus) {
+    const int64_t rem = w256 % cus;
+    return (rem != 0 && rem * 20 <= (int64_t)cus * 11) ? 4 : 8;
+  }
+  if (w256 >= cus * 7 / 8) return 8;
   // 16-bit types (round 6, tools/form_sweep.py): once the 128-row tiles outnumber the CUs -- where the key-split 8-wave form would need a
   // second round of workgroups -- the 256-row 8-wave workgroup wins from 132 workgroups on 256 CUs up, not only from 7/8 of the CUs:
   // rows <= 128 bytes against two 4-wave workgroups per CU -5 ... -9 % (profiles/r06_form_sweep_d64_b.txt), D = 96 / 128 (lean form)
   // against the key-split form -25 ... -35 % (profiles/r06_form_sweep_d128_b.txt)
   if (bits16) {
     const int MT4 = (rows + 127) / 128;
-    if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cu_count()) return 8;
+    if (batch_heads * (causal ? (MT4 + 1) / 2 : MT4) > cus) return 8;
   }
   return 4;
 }
@@ -1362,7 +1372,7 @@ template <typename T, int D, bool BIAS>
 static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   if (p.dyn) {                  // per-row exponent reference (online): the prefetching form, 8 waves where they fit two per SIMD
     if constexpr (D * Traits<T>::ES <= 128) {
-      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
+      if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2, true) == 8) return launch_fwd_nw<T, D, BIAS, 8, true>(p, s);
     } else if constexpr (fwd_lean<T, D, BIAS>()) {
       if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, true) == 8) return launch_fwd_nw<T, D, BIAS, 8, true, true>(p, s);
     }
@@ -1391,7 +1401,7 @@ static hipError_t launch_fwd_b(const FwdParams& p, hipStream_t s) {
   }
 #endif
   if constexpr (D * Traits<T>::ES <= 128) {      // two waves per SIMD whatever the grid (<= 256 registers with all prefetches)
-    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
+    if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, Traits<T>::ES == 2, true) == 8) return launch_fwd_nw<T, D, BIAS, 8, false>(p, s);
   } else if constexpr (fwd_lean<T, D, BIAS>()) {
     // the lean form needs its partner wave: one 8-wave workgroup per CU (a grid with two 4-wave workgroups per CU always has that)
     if (row_tile_waves((int64_t)p.B * p.H, p.N, p.causal, true) == 8) return launch_fwd_nw<T, D, BIAS, 8, false, true>(p, s);
