@@ -1313,13 +1313,25 @@ __global__ void __launch_bounds__(256) fwd_combine_kernel(const FwdParams p) {
   float acc[8], lt = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int sidx = 0; sidx < p.splits; ++sidx) {
-    const int64_t prow = (int64_t)sidx * rows + row;
-    lt += p.ws_l[prow];
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws_o + prow * D + 8 * c);
-    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.ws_o + prow * D + 8 * c + 4);
+  // four splits' loads in flight before the first add (the loop over a run-time count left one dependent triple of loads in flight: the whole
+  // kernel is this loop); same summation order, bit-identical (round 6)
+  for (int s0 = 0; s0 < p.splits; s0 += 4) {
+    f32x4 a[4], b2[4];
+    float lv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b2[e]; }
+    for (int u = 0; u < 4; ++u) {
+      const int64_t prow = (int64_t)min(s0 + u, p.splits - 1) * rows + row;      // (clamped: a repeated load, not added)
+      lv[u] = p.ws_l[prow];
+      a[u] = *reinterpret_cast<const f32x4*>(p.ws_o + prow * D + 8 * c);
+      b2[u] = *reinterpret_cast<const f32x4*>(p.ws_o + prow * D + 8 * c + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < p.splits) {
+        lt += lv[u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += a[u][e]; acc[4 + e] += b2[u][e]; }
+      }
   }
   const float inv = 1.f / fmaxf(lt, p.l_eps);
   const int64_t bh = row / p.N;

@@ -87,9 +87,11 @@ struct RowMap {
 // ---------------------------------------------------------------------------------------------
 // forward, group size multiple of 8
 // ---------------------------------------------------------------------------------------------
-constexpr int kNormUnroll = 4;      // row chunks per block: all loads of a thread are issued before the first use
-// Small tensors (single-headed K at C5: 8192 rows = 64 blocks of 4 chunks on 256 CUs) take one chunk per thread instead, so the grid
-// still reaches every CU: the pass is latency-bound there, not bandwidth-bound.
+// Row chunks (16 bytes) per thread.  Rounds 1 - 5 took four (all loads of a thread issued before the first use) and, since the first half
+// of round 6, one on grids below two blocks per CU; re-measured over sizes in round 6: ONE is never slower and 7 - 18 % faster on the large
+// tensors too (C3's k: 11.7 -> 10.9 us, D = 128: 21.2 -> 18.0, (8,8,4096,64): 21.2 -> 17.4; two: level with one; three, eight: slower --
+// profiles/r06_ab_norm_unroll.txt): four times the blocks in flight hide the HBM latency better than four loads per thread.
+constexpr int kNormUnroll = 1;
 template <typename T, int UNROLL = kNormUnroll>
 FCSA_DEV void l2norm_rows(const NormParams& p, int block) {
   const int64_t nrows = (int64_t)p.B * p.H * p.L;
@@ -286,14 +288,9 @@ static hipError_t launch_l2norm_t(const NormParams& p, hipStream_t s) {
   if (nrows == 0) return hipSuccess;
   const int dg = p.D / p.G;
   if (dg % 8 == 0) {
-    const int rows_per_wave_pass = 4 * (64 / (p.D / 8));
-    const int rows_per_block = kNormUnroll * rows_per_wave_pass;
+    const int rows_per_block = kNormUnroll * 4 * (64 / (p.D / 8));
     const int64_t blocks = (nrows + rows_per_block - 1) / rows_per_block;
-    if (blocks < 2 * cu_count()) {      // a grid that would leave CUs idle: one chunk per thread
-      hipLaunchKernelGGL((l2norm_kernel<T, 1>), dim3((unsigned)((nrows + rows_per_wave_pass - 1) / rows_per_wave_pass)), dim3(256), 0, s, p);
-    } else {
-      hipLaunchKernelGGL(l2norm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    }
+    hipLaunchKernelGGL(l2norm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, p);
   } else {
     const int64_t total = nrows * p.G;
     hipLaunchKernelGGL(l2norm_generic_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
