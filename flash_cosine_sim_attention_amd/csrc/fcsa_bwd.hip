@@ -269,16 +269,18 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
   const int npass = (causal && (MT - 1 - pt) != pt) ? 2 : 1;
-  // split-key launches (gridDim.y = p.dq_splits > 1; never causal): this workgroup sees the keys [k_lo, k_lo + Mk) only and
+  // split-key launches (gridDim.y = p.dq_splits > 1): this workgroup sees the keys [k_lo, k_lo + Mk) only and
   // writes its partial dQ^ (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
   // Like the forward's split (fcsa_fwd.hip), for grids whose row tiles cannot fill the chip.
+  // Causal launches (round 6) split the key range of EACH row tile -- the keys up to its diagonal -- so the window is set per pass
+  // (geometry below): the pair (MT-1-pt, pt) keeps its constant work, 1 / dq_splits of it per workgroup.
   int k_lo = 0, Mk = p.M;
-  if (p.dq_splits > 1) {
+  if (p.dq_splits > 1 && !causal) {
     const int tps = ((p.M + BN - 1) / BN + p.dq_splits - 1) / p.dq_splits;      // 64-key tiles per split
     k_lo = (int)blockIdx.y * tps * BN;
     Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
   }
-  const int diff = p.M - p.N - k_lo;
+  int diff = p.M - p.N - k_lo;
   const uint32_t ncm = causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
@@ -322,6 +324,15 @@ __global__ void __launch_bounds__(NW * 64, (TWO ? 2 : 1)) bwd_dq_kernel(const Bw
   auto geometry = [&](int pass_, int& m0_, int& nt_) {
     const int mt_ = causal ? (pass_ == 0 ? MT - 1 - pt : pt) : pt;      // heavy tile first
     m0_ = mt_ * BM;
+    if constexpr (!KM && !KSPLIT && !BIAS && NW == 4) {      // (the form causal split launches take; the others compile to what they were)
+      if (p.dq_splits > 1 && causal) {            // this row tile's visible keys [0, vis), split over gridDim.y workgroups
+        const int vis = max(0, min(p.M, m0_ + BM + p.M - p.N));
+        const int tps = max(1, ((vis + BN - 1) / BN + p.dq_splits - 1) / p.dq_splits);
+        k_lo = min((int)blockIdx.y * tps * BN, p.M);
+        Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
+        diff = p.M - p.N - k_lo;
+      }
+    }
     int last_key = Mk - 1;
     if (causal) last_key = min(last_key, m0_ + BM - 1 + diff);
     nt_ = last_key < 0 ? 0 : last_key / BN + 1;
@@ -1178,11 +1189,14 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
 #define FCSA_PASS_MARK(k) ((void)0)
 #endif
   // (batch, head) is fixed for the workgroup: everything that does not depend on the pass is set up once
-  // split-query launches (gridDim.y = p.dkv_splits > 1; never causal): this workgroup sees the query tiles [t_lo, QT) of its key tile
+  // split-query launches (gridDim.y = p.dkv_splits > 1): this workgroup sees the query tiles [t_lo, QT) of its key tile
   // only and writes its partial dK^ / dV (f32) to slab blockIdx.y; the finalize kernel sums the slabs (and applies the l2norm backward).
   // For key grids that cannot fill the chip: few keys, many queries (the mirror image of the split-key forward / dQ).
-  int QT = (p.N + BMQ - 1) / BMQ, t_lo = 0;
-  if (p.dkv_splits > 1) {
+  // Causal launches (round 6) split the query range of EACH key tile -- the tiles from its diagonal down -- so the window [t0, QT) is set
+  // per pass (geometry below): the pair (pt, KT-1-pt) keeps its constant work, 1 / dkv_splits of it per workgroup.
+  const int QT_all = (p.N + BMQ - 1) / BMQ;
+  int QT = QT_all, t_lo = 0;
+  if (p.dkv_splits > 1 && !causal) {
     const int tps = (QT + p.dkv_splits - 1) / p.dkv_splits;      // query tiles per split
     t_lo = (int)blockIdx.y * tps;
     QT = min(QT, t_lo + tps);
@@ -1246,6 +1260,13 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= kDkv2WBytes ||
     const int kt_ = causal ? (pass_ == 0 ? pt : KT - 1 - pt) : pt;      // heavy tile first
     n0_ = kt_ * BNK;
     t0_ = causal ? max(0, n0_ - diff) / BMQ : t_lo;
+    if constexpr (!KM && NW == 4 && !LEAN && !QSPLIT && !BIAS) {      // (the form causal split launches take; the others compile to what they were)
+      if (p.dkv_splits > 1 && causal) {
+        const int tps = max(1, (QT_all - t0_ + p.dkv_splits - 1) / p.dkv_splits);
+        t0_ = min(QT_all, t0_ + (int)blockIdx.y * tps);
+        QT = min(QT_all, t0_ + tps);
+      }
+    }
   };
   // requests of a pass that need nothing but a free staging buffer 0: first Q / dO tile (DMA form) with its per-query terms, this
   // lane's K / V fragments, its key-mask byte and the inverse norms its epilogue will use

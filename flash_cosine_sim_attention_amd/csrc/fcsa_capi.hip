@@ -218,10 +218,17 @@ static int split_by_target(const fcsa_problem& p, int64_t wgs, int len) {
 
 // Split-key dQ: not causal, every split keeps >= 512 keys.  C4 (1 x 8 heads x 1024 queries, 8192 keys): 64 row tiles, 8 splits.
 int backward_dq_splits(const fcsa_problem& p) {
-  if (p.causal) return 1;
 #ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/split_sweep.py, dev/fcsa_sweep_env.h): the count from the environment, per call
-  if (const int v = fcsa_dev::env_int("FCSA_DQ_SPLITS"); v >= 1) return std::min(std::min(v, 16), std::max(1, p.k_len / 64));
+  if (const int v = fcsa_dev::env_int("FCSA_DQ_SPLITS"); v >= 1 && (!p.causal || (elem_size(p.dtype) == 2 && p.q_len >= 256)))
+    return std::min(std::min(v, 16), std::max(1, p.k_len / 64));
 #endif
+  if (p.causal) {
+    // Causal (round 6), like the forward: the workgroups are PAIRS of 128-row tiles; where the pairs cannot fill the chip each row tile's
+    // key range (up to its diagonal) is split.  16-bit only.
+    if (elem_size(p.dtype) != 2 || p.q_len < 256) return 1;
+    const int mt = (p.q_len + 127) / 128;
+    return best_split(kSplitDq, false, p.dim_head, (int64_t)p.batch * p.heads * ((mt + 1) / 2), (int64_t)p.batch * p.heads * p.q_len, p.k_len);
+  }
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
   if (elem_size(p.dtype) == 2) return best_split(kSplitDq, false, p.dim_head, wgs, (int64_t)p.batch * p.heads * p.q_len, p.k_len);
   return split_by_target(p, wgs, p.k_len);
@@ -231,10 +238,19 @@ int backward_dq_splits(const fcsa_problem& p) {
 // K/V with heads (the single-headed form already reduces over slabs), every split keeps >= 512 queries.  Partial dK^ / dV go to f32
 // slabs [batch * heads][split][M][D] and the finalize kernel sums them (and applies the l2norm backward to dK^).
 int backward_dkv_splits(const fcsa_problem& p) {
-  if (p.causal || p.kv_heads != p.heads) return 1;
+  if (p.kv_heads != p.heads) return 1;
 #ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only
-  if (const int v = fcsa_dev::env_int("FCSA_DKV_SPLITS"); v >= 1) return std::min(std::min(v, 16), std::max(1, p.q_len / 64));
+  if (const int v = fcsa_dev::env_int("FCSA_DKV_SPLITS"); v >= 1 && (!p.causal || (elem_size(p.dtype) == 2 && p.k_len >= 256)))
+    return std::min(std::min(v, 16), std::max(1, p.q_len / 64));
 #endif
+  if (p.causal) {
+    // Causal (round 6): the workgroups are PAIRS of 128-key tiles; where the pairs cannot fill the chip each key tile's query range (from
+    // its diagonal down) is split.  16-bit only.
+    if (elem_size(p.dtype) != 2 || p.k_len < 256) return 1;
+    const int kt = (p.k_len + 127) / 128;
+    return best_split(kSplitDkv, false, p.dim_head, (int64_t)p.batch * p.heads * ((kt + 1) / 2), (int64_t)p.batch * p.heads * p.k_len,
+                      std::min(p.q_len, p.k_len));      // (a key tile sees the queries from its diagonal down: at most k_len of them)
+  }
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.k_len + 127) / 128);
   if (elem_size(p.dtype) == 2) return best_split(kSplitDkv, false, p.dim_head, wgs, (int64_t)p.batch * p.heads * p.k_len, p.q_len);
   return split_by_target(p, wgs, p.q_len);
@@ -370,11 +386,22 @@ int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_
   return timed("l2norm", "l2norm", s, [&] { return fcsa::launch_l2norm(dtype, np, s); });
 }
 
-// Split-key forward (the count: best_split above): only where the 128-row tiles cannot fill the chip, the problem is not causal (key
-// ranges of a causal row tile are short and uneven), the static exponent shift applies (partials with a common shift add up exactly)
-// and every split keeps >= 512 keys.
+// Split-key forward (the count: best_split above): only where the 128-row tiles (causal: pairs of them) cannot fill the chip, the static
+// exponent shift applies (partials with a common shift add up exactly) and every split keeps >= 512 keys.
 static int forward_splits(const fcsa_problem& p) {
-  if (p.causal || dynamic_shift(p, false)) return 1;      // (never called with a bias: fcsa_forward only splits bias-free problems)
+  if (dynamic_shift(p, false)) return 1;      // (never called with a bias: fcsa_forward only splits bias-free problems)
+  if (p.causal) {
+    // Causal (round 6): the workgroups are PAIRS of 128-row tiles (constant work: about k_len + 128 keys each); where the pairs cannot fill
+    // the chip -- one sequence of 4096 with 8 heads is 128 pairs on 256 CUs, and takes as long as two sequences -- each row tile's key range
+    // (up to its diagonal) is split.  16-bit only (the form rule of the model); the count from the same model with the pair as the tile.
+    if (elem_size(p.dtype) != 2 || p.q_len < 256) return 1;
+    const int mt = (p.q_len + 127) / 128;
+    const int64_t pairs = (int64_t)p.batch * p.heads * ((mt + 1) / 2);
+#ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only
+    if (const int v = fcsa_dev::env_int("FCSA_SPLITS"); v >= 1) return std::min(std::min(v, 16), std::max(1, p.k_len / 64));
+#endif
+    return best_split(kSplitFwd, true, p.dim_head, pairs, (int64_t)p.batch * p.heads * p.q_len, p.k_len);
+  }
   const int64_t wgs = (int64_t)p.batch * p.heads * ((p.q_len + 127) / 128);
   if (wgs <= 0) return 1;
 #ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only
@@ -523,7 +550,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   // (batch * head) row block); otherwise the unsplit kernel runs
   const bool dq_flat = a->dq.stride0 == (int64_t)p.heads * a->dq.stride1;
   const bool want_dbias = a->attn_bias != nullptr && a->d_bias != nullptr;
-  const int dq_splits = (L.dq_splits > 1 && dq_flat) ? L.dq_splits : 1;
+  const int dq_splits = (L.dq_splits > 1 && dq_flat && !(p.causal && a->attn_bias != nullptr)) ? L.dq_splits : 1;      // (causal splits: bias-free kernels only)
   const bool dq_slab = dq_splits > 1 || (p.l2norm_qk != 0 && !L.fuse_norm);
   bp.dq_splits = dq_splits;
   bp.dq_split_stride = (int64_t)p.q_len * p.dim_head * 4;

@@ -499,15 +499,17 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   block_to_work(blockIdx.x, p.B * p.H, PT, bh, pt);
   const int b = bh / p.H, h = bh % p.H;
   const int npass = (causal && (MT - 1 - pt) != pt) ? 2 : 1;
-  // split-key launches (gridDim.y = p.splits > 1, never causal / bias / dynamic shift): this workgroup sees the keys
-  // [k_lo, k_lo + Mk) only and writes un-normalised partials; everything below works on that sub-problem
+  // split-key launches (gridDim.y = p.splits > 1, never bias / dynamic shift): this workgroup sees the keys [k_lo, k_lo + Mk) only and
+  // writes un-normalised partials; everything below works on that sub-problem.  Causal launches (round 6) split the key range of EACH row
+  // tile -- the keys up to its diagonal -- so the ranges are set per pass (below): the pair (MT-1-pt, pt) keeps its constant work, 1 / splits
+  // of it per workgroup
   int k_lo = 0, Mk = p.M;
-  if (p.splits > 1) {
+  if (p.splits > 1 && !causal) {
     const int tps = ((p.M + BN - 1) / BN + p.splits - 1) / p.splits;      // 64-key tiles per split
     k_lo = (int)blockIdx.y * tps * BN;
     Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
   }
-  const int diff = p.M - p.N - k_lo;              // cu:1097 seq_len_diff (in the sub-problem's key numbering)
+  int diff = p.M - p.N - k_lo;                    // cu:1097 seq_len_diff (in the sub-problem's key numbering)
   const uint32_t ncm = causal ? 0u : 0xffffffffu;   // OR-ed into the causal bit mask: all ones when not causal
   Trace ts;
   ts.reset();
@@ -532,6 +534,13 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
   const int m0 = mt * BM;
   const int mw = m0 + rwave * 32;                 // first query row of this wave
   const int i = mw + (lane & 31);                 // this lane's query row
+  if (p.splits > 1 && causal) {                   // this row tile's visible keys [0, vis), split over gridDim.y workgroups
+    const int vis = max(0, min(p.M, m0 + BM + p.M - p.N));
+    const int tps = max(1, ((vis + BN - 1) / BN + p.splits - 1) / p.splits);
+    k_lo = min((int)blockIdx.y * tps * BN, p.M);
+    Mk = max(0, min(p.M, k_lo + tps * BN) - k_lo);
+    diff = p.M - p.N - k_lo;
+  }
 
   // key tiles this workgroup needs
   int last_key = Mk - 1;
@@ -868,6 +877,7 @@ __global__ void __launch_bounds__(NW * 64, ((D * Traits<T>::ES <= 128 || LEAN) ?
       if (fa.hi == 0) p.ws_l[prow] = lt;
       store_row_tile<T, D>(reinterpret_cast<char*>(p.ws_o + prow * D), o, 1.f, fa.hi, true);
     }
+    if (pass + 1 < npass) __syncthreads();      // (causal pairs: the barrier the key-split form's other half waits at, and the one that frees the LDS)
     continue;
   }
   const float inv = 1.f / fmaxf(lt, p.l_eps);     // cu:1239 (constants::eps, cu:83), rescaled with the shift

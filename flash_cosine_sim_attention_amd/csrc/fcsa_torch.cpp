@@ -193,7 +193,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> forward(const Tensor&
   a.norm.rk = (l2norm_qk && need_backward) ? rk.data_ptr<float>() : nullptr;
   Tensor ws;
   a.workspace = nullptr; a.workspace_bytes = 0;
-  if (!causal && c.B * c.H * c.N < 32768) {       // only grids that cannot fill the chip ever split the key range (< 256 row tiles of 128)
+  if (c.B * c.H * c.N < (causal ? 65536 : 32768)) {   // only grids that cannot fill the chip ever split the key range (< 256 row tiles of 128; causal: < 256 PAIRS of them)
     const size_t need = g_abi.forward_ws(&a.p);
     if (need > 0) {
       ws = at::empty({(int64_t)need}, opt.dtype(at::kByte));

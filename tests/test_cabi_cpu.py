@@ -140,7 +140,7 @@ def test_backward_workspace_single_head_non_causal_stays_small(lib):
 
 
 def test_backward_workspace_split_query_dkv(lib):
-    """Split-query dK/dV (few keys, many queries, not causal, K/V with heads): dkv_splits f32 slabs for dk and for dv, sized by the
+    """Split-query dK/dV (few keys, many queries, K/V with heads): dkv_splits f32 slabs for dk and for dv, sized by the
     rule the launch uses (fcsa_capi.hip backward_dkv_splits -> best_split: the argmin of the cost model over 1 .. 16)."""
     al = lambda x: (x + 255) // 256 * 256
     # 1 x 8 heads x 1024 keys = 64 key tiles -> 4 splits of 2048 queries: 256 workgroups, one round (measured 53.3 us against 53.6 with
@@ -148,7 +148,7 @@ def test_backward_workspace_split_query_dkv(lib):
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)
     slab = 4 * 8 * 1024 * 64 * 4                                # splits x heads x M x D floats
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 8192 * 4) + al(slab) + al(slab)
-    # causal, single-headed K/V and key grids that fill the chip keep the unsplit kernel
+    # causal with more rows than keys (a key tile sees at most k_len = 1024 queries), single-headed K/V and key grids that fill the chip keep the unsplit kernel
     for kw in (dict(causal=1), dict(kv_heads=1)):
         q = _problem(**dict(dict(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1), **kw))
         single = 8 * 1024 * 64 * 4 if kw.get("kv_heads") == 1 else 0
@@ -191,8 +191,17 @@ def test_split_counts_follow_the_measured_tables(lib):
     assert _split_counts(lib, dtype=bf16, q_len=512, k_len=4096, dim_head=128, **H8) == (8, 8, 1)         # 256-byte rows, 32 row tiles
     assert _split_counts(lib, dtype=bf16, batch=2, heads=8, kv_heads=8, q_len=1024, k_len=2048, dim_head=128) == (2, 2, 1)
     assert _split_counts(lib, dtype=f16, batch=1, heads=4, kv_heads=4, q_len=300, k_len=16384, dim_head=64) == (16, 16, 1)
-    # invariants: never causal, never when the tiles fill the chip, every split keeps >= 512 positions of its loop
-    assert _split_counts(lib, dtype=f16, q_len=1024, k_len=8192, dim_head=64, causal=1, **H8) == (1, 1, 1)
+    # causal (round 6): the tiles are PAIRS of 128-position tiles and each tile's loop range up to / from its diagonal is split (k_len = q_len - 1
+    # below only keeps the workspace sizes invertible).  (1,4,4096,64): 64 pairs -> 4 splits each (forward 29.7 us against 45.1 un-split, dQ
+    # 37.4 / 55.9, dK/dV 43.6 / 61.7); (1,16,2048,64): 128 pairs of a 2048-position problem stay un-split (forward 30.5 us, two splits 33.1; dQ 37.6 /
+    # 38.8; dK/dV 41.3 / 44.7) -- profiles/r06_split_sweep_causal*.txt
+    assert _split_counts(lib, dtype=bf16, batch=1, heads=4, kv_heads=4, q_len=4096, k_len=4095, dim_head=64, causal=1) == (4, 4, 4)
+    assert _split_counts(lib, dtype=bf16, batch=1, heads=16, kv_heads=16, q_len=2048, k_len=2047, dim_head=64, causal=1) == (1, 1, 1)
+    assert _split_counts(lib, dtype=bf16, batch=1, heads=4, kv_heads=4, q_len=8192, k_len=8191, dim_head=128, causal=1) == (2, 2, 2)
+    assert _split_counts(lib, dtype=bf16, batch=1, heads=1, kv_heads=1, q_len=16384, k_len=16383, dim_head=64, causal=1) == (4, 8, 4)
+    assert _split_counts(lib, dtype=f16, q_len=1024, k_len=8192, dim_head=64, causal=1, **H8) == (8, 8, 1)      # more keys than rows: every row sees >= 7169 keys
+    assert _split_counts(lib, dtype=0, batch=1, heads=4, kv_heads=4, q_len=4096, k_len=4095, dim_head=64, causal=1) == (1, 1, 1)      # float32: causal problems are not split
+    # invariants: never when the tiles fill the chip, every split keeps >= 512 positions of its loop
     assert _split_counts(lib, dtype=f16, batch=4, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64) == (1, 1, 1)
     for M in (511, 1023, 1024, 1500, 2047, 4096, 5000):
         for tiles in (1, 7, 40, 100, 200):
@@ -229,7 +238,13 @@ def test_forward_workspace_formula(lib):
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(4 * 8 * 1024 * 64 * 4) + al(4 * 8 * 1024 * 4)
     p = _problem(batch=4, heads=8, kv_heads=8, q_len=1024, k_len=1024, dim_head=64)      # C2: 256 row tiles
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
-    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64, causal=1)
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=1024, dim_head=64, causal=1)      # causal: 32 pairs, but 1024 keys are one split's worth
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=4096, k_len=4096, dim_head=64, causal=1)      # round 6: 128 PAIRS of row tiles on 256 CUs -> 2 splits
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(2 * 8 * 4096 * 64 * 4) + al(2 * 8 * 4096 * 4)
+    p = _problem(batch=2, heads=8, kv_heads=8, q_len=4096, k_len=4096, dim_head=64, causal=1)      # 256 pairs: the chip is full
+    assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
+    p = _problem(batch=1, heads=8, kv_heads=8, q_len=4096, k_len=4096, dim_head=64, causal=1, dtype=0)     # float32: not split
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == 0
     p = _problem(batch=1, heads=2, kv_heads=2, q_len=8, k_len=4096, dim_head=128)        # 2 row tiles -> 8 splits of 512 keys
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(8 * 2 * 8 * 128 * 4) + al(8 * 2 * 8 * 4)

@@ -34,11 +34,35 @@ def _npf(t):
 
 @pytest.mark.parametrize("dtype,B,H,N,M,D,use_mask,single_kv,l2norm,groups", CASES)
 def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups):
+    _split_forward_case(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups, False)
+
+
+# Causal problems whose PAIRS of 128-row tiles cannot fill the chip (round 6): the key range of each row tile -- up to its diagonal -- is
+# split, so a workgroup of split y sees a different key window in each of its two passes and some windows are empty.  The same holds for
+# the backward of these problems: dQ splits each row tile's keys, dK/dV each key tile's queries (from its diagonal down).
+CAUSAL_CASES = [
+    # dtype, B, H, N,    M,    D,  single_kv, l2norm, groups
+    ("bf16", 1, 2, 2200, 2200, 64, False, True, 1),       # 9 pairs; ragged rows and keys
+    ("f16", 1, 3, 1500, 2600, 32, False, True, 1),        # M > N: every row sees the first 1100 keys as well
+    ("bf16", 2, 2, 3000, 2100, 128, False, True, 8),      # N > M: rows 0 .. 899 see no key at all (zeros), 256-byte rows
+    ("f16", 1, 4, 2300, 2300, 64, True, True, 1),         # single-headed K/V
+    ("bf16", 1, 1, 4096, 4096, 64, False, False, 1),      # q, k already normalised (the reference extension's contract); 16 pairs
+]
+
+
+@pytest.mark.parametrize("dtype,B,H,N,M,D,single_kv,l2norm,groups", CAUSAL_CASES)
+def test_causal_split_forward_matches_oracle(dtype, B, H, N, M, D, single_kv, l2norm, groups):
+    _split_forward_case(dtype, B, H, N, M, D, False, single_kv, l2norm, groups, True)
+
+
+def _split_forward_case(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups, causal):
     import flash_cosine_sim_attention_amd as F
     from flash_cosine_sim_attention_amd import _lib
     dt = DT[dtype]
-    prob = _lib.problem(dt, (B, H, 1 if single_kv else H, N, M, D), False, False, l2norm, groups, 8.0 if l2norm else 0.125)
+    prob = _lib.problem(dt, (B, H, 1 if single_kv else H, N, M, D), causal, False, l2norm, groups, 8.0 if l2norm else 0.125)
     assert _lib.load().fcsa_forward_workspace_bytes(C.byref(prob)) > 0, "case would not take the split-key path"
+    if causal and not single_kv:      # the causal cases also run the split-key dQ / split-query dK/dV kernels (f32 slabs behind delta in the workspace)
+        assert _lib.load().fcsa_backward_workspace_bytes(C.byref(prob)) > (B * H * N * 4 + 255) // 256 * 256, "case would not split the backward"
     g = torch.Generator(device="cuda").manual_seed(N * 7 + M)
     q = torch.randn((B, H, N, D), device="cuda", dtype=dt, generator=g)
     kv_shape = (B, M, D) if single_kv else (B, H, M, D)
@@ -53,12 +77,12 @@ def test_split_forward_matches_oracle(dtype, B, H, N, M, D, use_mask, single_kv,
         mask[:, 600:1100] = False            # a whole split (or most of it) without a valid key
     q.requires_grad_(); k.requires_grad_(); v.requires_grad_()
     scale = 8.0 if l2norm else 0.125
-    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups, l2norm_qk=l2norm)
+    o = F.flash_cosine_sim_attention(q, k, v, mask=mask, scale=scale, groups=groups, l2norm_qk=l2norm, causal=causal)
     do = torch.randn(o.shape, device="cuda", dtype=dt, generator=g)
     o.backward(do)
     torch.cuda.synchronize()
     mk = None if mask is None else _npf(mask).astype(bool)
-    kw = dict(mask=mk, scale=scale, groups=groups, l2norm_qk=l2norm)
+    kw = dict(mask=mk, scale=scale, groups=groups, l2norm_qk=l2norm, causal=causal)
     ro, _ = O.attention_forward_stats(_npf(q), _npf(k), _npf(v), **kw)
     atol, rtol = FWD_TOL[dtype]
     excess = (np.abs(_npf(o) - ro) - rtol * np.abs(ro)).max()

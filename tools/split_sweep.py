@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--shape", default="1,8,1024,64,8192")
 ap.add_argument("--splits", default="1,2,3,4,6,8,16")
+ap.add_argument("--causal", action="store_true", help="causal problems (each tile's loop range up to / from its diagonal is split)")
 ap.add_argument("--bwd", choices=["dq", "dkv"], help="sweep FCSA_DQ_SPLITS / FCSA_DKV_SPLITS of the backward instead (kernel + its share of finalize)")
 a = ap.parse_args()
 _torch_ops.load()
@@ -35,13 +36,14 @@ for shape in a.shape.split(":"):
         do = torch.randn(B, H, N, D, device="cuda", dtype=dt)
         var, other = ("FCSA_DQ_SPLITS", "FCSA_DKV_SPLITS") if a.bwd == "dq" else ("FCSA_DKV_SPLITS", "FCSA_DQ_SPLITS")
         os.environ.pop(other, None); os.environ.pop("FCSA_SPLITS", None); os.environ.pop("FCSA_KSPLIT", None)
+        if a.causal: os.environ[other] = "1"      # (the other kernel un-split: its finalize launch stays out of the second column)
         length = M if a.bwd == "dq" else N
         counts = [c for c in (int(x) for x in a.splits.split(",")) if c <= max(1, length // 64)]
         kern = "bwd_dq" if a.bwd == "dq" else "bwd_dkv"
         res, g0 = {c: [] for c in counts}, None
         def step():
             q.grad = k.grad = v.grad = None
-            F.flash_cosine_sim_attention(q, k, v).backward(do)
+            F.flash_cosine_sim_attention(q, k, v, causal=a.causal).backward(do)
         for r in range(a.rounds + 1):
             for c in counts:
                 os.environ[var] = str(c)
@@ -60,9 +62,10 @@ for shape in a.shape.split(":"):
                 st = {s_["name"]: s_["total_ms"] / a.steps * 1e3 for s_ in _lib.profile_collect()}
                 _lib.profile_enable(False)
                 res[c].append((st.get(kern, 0.0), st.get(kern, 0.0) + st.get("finalize", 0.0)))
-        os.environ.pop(var, None)
+        os.environ.pop(var, None); os.environ.pop(other, None)
         tiles = B * H * (((N if a.bwd == "dq" else M) + 127) // 128)
-        print(f"shape {shape} {a.dtype}: {a.bwd}, {tiles} tiles of 128; us per step, median over {a.rounds} rounds: kernel (kernel + every finalize launch of the step)")
+        if a.causal: tiles = B * H * ((((N if a.bwd == "dq" else M) + 127) // 128 + 1) // 2)
+        print(f"shape {shape} {a.dtype}{' causal' if a.causal else ''}: {a.bwd}, {tiles} tiles of 128{' (pairs)' if a.causal else ''}; us per step, median over {a.rounds} rounds: kernel (kernel + every finalize launch of the step)")
         print("   " + "  ".join(f"s{c}:{statistics.median(x[0] for x in res[c]):6.1f} ({statistics.median(x[1] for x in res[c]):6.1f})" for c in counts))
     cfgs = [] if a.bwd else [(s, ks) for s in (int(x) for x in a.splits.split(",")) for ks in ("0", "1") if s <= max(1, M // 64)]
     res = {c: [] for c in cfgs}
@@ -71,21 +74,21 @@ for shape in a.shape.split(":"):
         for c in cfgs:
             os.environ["FCSA_SPLITS"], os.environ["FCSA_KSPLIT"] = str(c[0]), c[1]
             with torch.no_grad():
-                for _ in range(3): o = F.flash_cosine_sim_attention(q, k, v)
+                for _ in range(3): o = F.flash_cosine_sim_attention(q, k, v, causal=a.causal)
                 torch.cuda.synchronize()
                 if r == 0:
                     if ref is None: ref = o.float().clone()
                     else: assert (o.float() - ref).abs().max().item() < 2e-3, (c, (o.float() - ref).abs().max().item())
                     continue
                 _lib.profile_enable(True)
-                for _ in range(a.steps): F.flash_cosine_sim_attention(q, k, v)
+                for _ in range(a.steps): F.flash_cosine_sim_attention(q, k, v, causal=a.causal)
                 torch.cuda.synchronize()
                 st = _lib.profile_collect()
                 _lib.profile_enable(False)
             res[c].append(sum(s["total_ms"] / s["calls"] * 1e3 for s in st if s["name"] in ("fwd",)))
     if a.bwd:
         continue
-    wgs = B * H * ((N + 127) // 128)
-    print(f"shape {shape} {a.dtype}: {wgs} row tiles of 128; forward (kernel + combine) us, median over {a.rounds} rounds; columns = splits, rows = form")
+    wgs = B * H * ((N + 127) // 128) if not a.causal else B * H * (((N + 127) // 128 + 1) // 2)
+    print(f"shape {shape} {a.dtype}{' causal' if a.causal else ''}: {wgs} row tiles of 128{' (pairs)' if a.causal else ''}; forward (kernel + combine) us, median over {a.rounds} rounds; columns = splits, rows = form")
     for ks in ("0", "1"):
         print(("4-wave     " if ks == "0" else "ksplit(8w) ") + "  ".join(f"s{c[0]}:{statistics.median(res[c]):6.1f}" for c in cfgs if c[1] == ks))
