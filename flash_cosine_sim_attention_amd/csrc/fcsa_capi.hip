@@ -156,7 +156,7 @@ struct BwdLayout {
 };
 
 // ---- split counts (forward keys / dQ keys / dK-dV queries) -------------------------------------------------------------------------
-// Where a non-causal problem's 128-position tiles cannot fill the chip, several workgroups share one tile's loop range and write f32
+// Where a problem's 128-position tiles (causal, since round 6: PAIRS of tiles) cannot fill the chip, several workgroups share one tile's loop range and write f32
 // partials that a second pass (fwd_combine_kernel / finalize) sums.  How many: rounds 2 - 5 took "enough workgroups for two per CU";
 // since round 6 the count is the argmin of a small cost model over s = 1 .. 16 (16-bit types; float32 keeps the old rule).  The model
 // prices, in microseconds on MI355X, what a launch with s splits costs:
@@ -216,7 +216,7 @@ static int split_by_target(const fcsa_problem& p, int64_t wgs, int len) {
   return s >= 2 ? (int)s : 1;
 }
 
-// Split-key dQ: not causal, every split keeps >= 512 keys.  C4 (1 x 8 heads x 1024 queries, 8192 keys): 64 row tiles, 8 splits.
+// Split-key dQ: every split keeps >= 512 keys.  C4 (1 x 8 heads x 1024 queries, 8192 keys): 64 row tiles, 8 splits.
 int backward_dq_splits(const fcsa_problem& p) {
 #ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only (tools/split_sweep.py, dev/fcsa_sweep_env.h): the count from the environment, per call
   if (const int v = fcsa_dev::env_int("FCSA_DQ_SPLITS"); v >= 1 && (!p.causal || (elem_size(p.dtype) == 2 && p.q_len >= 256)))
@@ -234,7 +234,7 @@ int backward_dq_splits(const fcsa_problem& p) {
   return split_by_target(p, wgs, p.k_len);
 }
 
-// Split-query dK/dV: the mirror image -- few keys, many queries (B * H * ceil(M / 128) key tiles cannot fill the chip), not causal,
+// Split-query dK/dV: the mirror image -- few keys, many queries (B * H * ceil(M / 128) key tiles cannot fill the chip),
 // K/V with heads (the single-headed form already reduces over slabs), every split keeps >= 512 queries.  Partial dK^ / dV go to f32
 // slabs [batch * heads][split][M][D] and the finalize kernel sums them (and applies the l2norm backward to dK^).
 int backward_dkv_splits(const fcsa_problem& p) {

@@ -49,7 +49,7 @@ struct BwdParams {
   void* d_bias;             // [Hb,N,M] in the bias dtype, written once per element by bwd_dbias_kernel, or nullptr
   int dq_splits;            // > 1: the dQ kernel splits the KEY range over gridDim.y workgroups that write partial f32 slabs
   int64_t dq_split_stride;  //      byte distance between the slabs of consecutive splits (dq then views slab 0)
-  int dkv_splits;           // > 1: the dK/dV kernel splits the QUERY range over gridDim.y workgroups (never causal), partial f32 slabs
+  int dkv_splits;           // > 1: the dK/dV kernel splits the QUERY range over gridDim.y workgroups, partial f32 slabs
   int64_t dkv_split_stride; //      byte distance between the dk (and dv) slabs of consecutive splits
   int B, H, N, M;
   int causal, bias_batch;

@@ -232,7 +232,7 @@ def test_scale_range(lib):
 
 
 def test_forward_workspace_formula(lib):
-    # split-key forward: only non-causal problems whose 128-row tiles cannot fill the chip, with >= 1024 keys
+    # split-key forward: only problems whose 128-row tiles (causal: pairs) cannot fill the chip, with >= 1024 keys
     al = lambda x: (x + 255) // 256 * 256
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=1024, k_len=8192, dim_head=64)      # C4: 64 row tiles -> 4 splits (256 8-wave workgroups)
     assert lib.fcsa_forward_workspace_bytes(C.byref(p)) == al(4 * 8 * 1024 * 64 * 4) + al(4 * 8 * 1024 * 4)

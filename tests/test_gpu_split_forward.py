@@ -1,5 +1,5 @@
 """Split-key forward (fcsa_fwd.hip: fwd_kernel with gridDim.y = splits + fwd_combine_kernel; chosen by fcsa_capi.hip
-forward_splits when a non-causal problem's 128-row tiles cannot fill the chip and the caller passes the optional
+forward_splits when a problem's 128-row tiles (causal: pairs of them) cannot fill the chip and the caller passes the optional
 workspace): parity with the float64 oracle, forward and -- through the saved inv_l -- backward."""
 import ctypes as C
 
@@ -121,7 +121,7 @@ def test_split_and_unsplit_agree_through_the_c_abi():
     assert ((l0 - l1).abs() / l0.abs()).max().item() <= 1e-5
 
 
-# Split-query dK/dV (fcsa_capi.hip backward_dkv_splits: few keys, many queries, not causal, K/V with heads): the dK/dV kernel runs
+# Split-query dK/dV (fcsa_capi.hip backward_dkv_splits: few keys, many queries, K/V with heads; the causal form: CAUSAL_CASES above): the dK/dV kernel runs
 # gridDim.y query ranges that write partial f32 slabs, one finalize launch sums them (and applies the l2norm backward to dK^).
 # Through the public op, i.e. with the workspace the compiled binding sizes from fcsa_backward_workspace_bytes.
 SPLIT_QUERY_CASES = [
