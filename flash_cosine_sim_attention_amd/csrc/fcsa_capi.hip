@@ -238,7 +238,7 @@ int backward_dq_splits(const fcsa_problem& p) {
 // K/V with heads (the single-headed form already reduces over slabs), every split keeps >= 512 queries.  Partial dK^ / dV go to f32
 // slabs [batch * heads][split][M][D] and the finalize kernel sums them (and applies the l2norm backward to dK^).
 int backward_dkv_splits(const fcsa_problem& p) {
-  if (p.kv_heads != p.heads) return 1;
+  // (single-headed K/V, round 6: split like any other problem -- its per-head slabs simply become heads x splits slabs for the same finalize launch)
 #ifdef FCSA_VAR_SPLIT_ENV      // sweep builds only
   if (const int v = fcsa_dev::env_int("FCSA_DKV_SPLITS"); v >= 1 && (!p.causal || (elem_size(p.dtype) == 2 && p.k_len >= 256)))
     return std::min(std::min(v, 16), std::max(1, p.q_len / 64));
@@ -556,7 +556,7 @@ int fcsa_backward(const fcsa_backward_args* a) {
   bp.dq_split_stride = (int64_t)p.q_len * p.dim_head * 4;
   // split-query dK/dV: same condition on dk / dv (flat (batch, head) index for the finalize kernel); the bias form keeps the unsplit kernel
   const bool dkv_flat = a->dk.stride0 == (int64_t)p.heads * a->dk.stride1 && a->dv.stride0 == (int64_t)p.heads * a->dv.stride1;
-  const int dkv_splits = (L.dkv_splits > 1 && dkv_flat && a->attn_bias == nullptr) ? L.dkv_splits : 1;
+  const int dkv_splits = (L.dkv_splits > 1 && (dkv_flat || single) && a->attn_bias == nullptr) ? L.dkv_splits : 1;
   const bool dk_slab = dkv_splits > 1 || single || (p.l2norm_qk != 0 && !L.fuse_norm);
   const bool dv_slab = dkv_splits > 1 || single;
   bp.dkv_splits = dkv_splits;
@@ -620,15 +620,15 @@ int fcsa_backward(const fcsa_backward_args* a) {
     nb.dx = view(a->dq, es);
     nb.dx.sb = nb.dx.sh;          // flat (batch * head) index: stride0 == heads * stride1 (checked above)
     nb.dx.sh = 0;
-    if (int rc = timed("finalize", "finalize dq (splits)", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
-    nb.B = p.batch;
   } else if (dq_slab) {
     nb.slab = ws + L.dq_slab; nb.slab_f32 = 1; nb.HS = p.heads; nb.HO = p.heads; nb.L = p.q_len;
     nb.xn = static_cast<const char*>(a->norm.qn); nb.inv_norm = a->norm.rq; nb.G = p.groups;
     nb.xn_scale = 1.f / (p.scale * kLog2e);           // qn holds c1 * q^
     nb.dx = view(a->dq, es);
-    if (int rc = timed("finalize", "finalize dq", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nb, s); })) return rc;
   }
+  // (the dq pass is launched below, together with the dk / dv passes where there are any: one grid instead of two or three)
+  const fcsa::NormBwdParams nq = nb;
+  nb.B = p.batch;
   fcsa::NormBwdParams nk = nb, nv = nb;
   if (dk_slab) {
     nk.slab = ws + L.dk_slab; nk.slab_f32 = 1; nk.HS = p.heads; nk.HO = p.kv_heads; nk.L = p.k_len;
@@ -644,17 +644,30 @@ int fcsa_backward(const fcsa_backward_args* a) {
   }
   if (dkv_splits > 1) {         // the splits are the "heads" of a flat (batch * head) batch, summed down to one
     for (fcsa::NormBwdParams* n : {&nk, &nv}) {
+      if (single) {               // slabs [batch][heads x splits][M][D] summed down to the one K/V head
+        n->HS = p.heads * dkv_splits; n->HO = 1;
+        continue;
+      }
       n->B = p.batch * p.heads; n->HS = dkv_splits; n->HO = 1;
       n->dx.sb = n->dx.sh;        // flat (batch * head) index: stride0 == heads * stride1 (checked above)
       n->dx.sh = 0;
     }
   }
-  if (dk_slab && dv_slab) {      // single-headed K/V, split-query dK/dV: both reductions in one launch
-    if (int rc = timed("finalize", "finalize dk+dv", s, [&] { return fcsa::launch_l2norm_bwd_pair(p.dtype, nk, nv, s); })) return rc;
-  } else if (dk_slab) {
-    if (int rc = timed("finalize", "finalize dk", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nk, s); })) return rc;
-  } else if (dv_slab) {
-    if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nv, s); })) return rc;
+  if (dq_slab && dk_slab && dv_slab) {      // causal problems on small grids (dQ and dK/dV both split), split dQ with single-headed K/V: one launch
+    if (int rc = timed("finalize", "finalize dq+dk+dv", s, [&] { return fcsa::launch_l2norm_bwd_triple(p.dtype, nq, nk, nv, s); })) return rc;
+  } else if (dq_slab && dk_slab) {          // l2norm groups that are not 8 * 2^k features wide
+    if (int rc = timed("finalize", "finalize dq+dk", s, [&] { return fcsa::launch_l2norm_bwd_pair(p.dtype, nq, nk, s); })) return rc;
+  } else {
+    if (dq_slab) {
+      if (int rc = timed("finalize", "finalize dq", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nq, s); })) return rc;
+    }
+    if (dk_slab && dv_slab) {      // single-headed K/V, split-query dK/dV: both reductions in one launch
+      if (int rc = timed("finalize", "finalize dk+dv", s, [&] { return fcsa::launch_l2norm_bwd_pair(p.dtype, nk, nv, s); })) return rc;
+    } else if (dk_slab) {
+      if (int rc = timed("finalize", "finalize dk", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nk, s); })) return rc;
+    } else if (dv_slab) {
+      if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nv, s); })) return rc;
+    }
   }
   return FCSA_OK;
 }

@@ -135,5 +135,6 @@ hipError_t launch_l2norm(int dtype, const NormParams& p, hipStream_t s);
 hipError_t launch_l2norm_pair(int dtype, const NormParams& a, const NormParams& b, hipStream_t s);   // q and k in one grid
 hipError_t launch_l2norm_bwd(int dtype, const NormBwdParams& p, hipStream_t s);
 hipError_t launch_l2norm_bwd_pair(int dtype, const NormBwdParams& a, const NormBwdParams& b, hipStream_t s);   // two passes, one grid
+hipError_t launch_l2norm_bwd_triple(int dtype, const NormBwdParams& a, const NormBwdParams& b, const NormBwdParams& c, hipStream_t s);   // three
 
 }  // namespace fcsa

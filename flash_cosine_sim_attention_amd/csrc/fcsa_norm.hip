@@ -242,6 +242,15 @@ __global__ void __launch_bounds__(256) l2norm_bwd_pair_kernel(const NormBwdParam
   else l2norm_bwd_rows<T>(b, blockIdx.x - blocks_a);
 }
 
+// three passes (dq, dk, dv slabs of a backward whose dQ AND dK/dV launches were split -- causal problems on small grids) in one grid
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_triple_kernel(const NormBwdParams a, const NormBwdParams b, const NormBwdParams c, const int blocks_a,
+                                                                const int blocks_ab) {
+  if ((int)blockIdx.x < blocks_a) l2norm_bwd_rows<T>(a, blockIdx.x);
+  else if ((int)blockIdx.x < blocks_ab) l2norm_bwd_rows<T>(b, blockIdx.x - blocks_a);
+  else l2norm_bwd_rows<T>(c, blockIdx.x - blocks_ab);
+}
+
 // finalize, any group size: one thread per (row, group)
 template <typename T>
 __global__ void __launch_bounds__(256) l2norm_bwd_generic_kernel(const NormBwdParams p) {
@@ -362,6 +371,29 @@ hipError_t launch_l2norm_bwd_pair(int dtype, const NormBwdParams& a, const NormB
   if (dtype == 2) return launch_l2norm_bwd_pair_t<BF16>(a, b, s);
   if (dtype == 1) return launch_l2norm_bwd_pair_t<F16>(a, b, s);
   if (dtype == 0) return launch_l2norm_bwd_pair_t<F32>(a, b, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t launch_l2norm_bwd_triple_t(const NormBwdParams& a, const NormBwdParams& b, const NormBwdParams& c, hipStream_t s) {
+  const int rows_per_block = 4 * (64 / (a.D / 8));
+  auto blocks = [&](const NormBwdParams& p) { return ((int64_t)p.B * p.HO * p.L + rows_per_block - 1) / rows_per_block; };
+  const int64_t ba = blocks(a), bb = blocks(b), bc = blocks(c);
+  if (ba + bb + bc == 0) return hipSuccess;
+  hipLaunchKernelGGL(l2norm_bwd_triple_kernel<T>, dim3((unsigned)(ba + bb + bc)), dim3(256), 0, s, a, b, c, (int)ba, (int)(ba + bb));
+  return hipGetLastError();
+}
+
+// three passes in one launch under the pair's conditions, else one launch + a pair
+hipError_t launch_l2norm_bwd_triple(int dtype, const NormBwdParams& a, const NormBwdParams& b, const NormBwdParams& c, hipStream_t s) {
+  auto rows_ok = [](const NormBwdParams& p) { return p.xn == nullptr || (p.D / p.G) % 8 == 0; };
+  if (!rows_ok(a) || !rows_ok(b) || !rows_ok(c) || a.D != b.D || a.D != c.D) {
+    const hipError_t e = launch_l2norm_bwd(dtype, a, s);
+    return e != hipSuccess ? e : launch_l2norm_bwd_pair(dtype, b, c, s);
+  }
+  if (dtype == 2) return launch_l2norm_bwd_triple_t<BF16>(a, b, c, s);
+  if (dtype == 1) return launch_l2norm_bwd_triple_t<F16>(a, b, c, s);
+  if (dtype == 0) return launch_l2norm_bwd_triple_t<F32>(a, b, c, s);
   return hipErrorInvalidValue;
 }
 

@@ -148,11 +148,12 @@ def test_backward_workspace_split_query_dkv(lib):
     p = _problem(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)
     slab = 4 * 8 * 1024 * 64 * 4                                # splits x heads x M x D floats
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(8 * 8192 * 4) + al(slab) + al(slab)
-    # causal with more rows than keys (a key tile sees at most k_len = 1024 queries), single-headed K/V and key grids that fill the chip keep the unsplit kernel
-    for kw in (dict(causal=1), dict(kv_heads=1)):
-        q = _problem(**dict(dict(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1), **kw))
-        single = 8 * 1024 * 64 * 4 if kw.get("kv_heads") == 1 else 0
-        assert lib.fcsa_backward_workspace_bytes(C.byref(q)) == al(8 * 8192 * 4) + 2 * al(single)
+    # single-headed K/V (round 6): split the same way -- heads x splits slabs per gradient instead of heads
+    q = _problem(batch=1, heads=8, kv_heads=1, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(q)) == al(8 * 8192 * 4) + 2 * al(slab)
+    # causal with more rows than keys (a key tile sees at most k_len = 1024 queries) and key grids that fill the chip keep the unsplit kernel
+    q = _problem(batch=1, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1, causal=1)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(q)) == al(8 * 8192 * 4)
     p = _problem(batch=4, heads=8, kv_heads=8, q_len=8192, k_len=1024, dim_head=64, dtype=2, l2norm_qk=1)      # 256 key tiles
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(4 * 8 * 8192 * 4)
     # 2 heads x 4 key tiles of 256-byte rows = 8 workgroups: as many splits as keep 512 queries each (4096 / 512 = 8)

@@ -55,12 +55,25 @@ def test_causal_split_forward_matches_oracle(dtype, B, H, N, M, D, single_kv, l2
     _split_forward_case(dtype, B, H, N, M, D, False, single_kv, l2norm, groups, True)
 
 
-def _split_forward_case(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups, causal):
+@pytest.mark.parametrize("dtype,B,H,N,M,D,use_mask,l2norm,groups,causal", [
+    ("bf16", 1, 4, 3000, 200, 64, False, True, 1, False),       # 8 key tiles, 5 query splits: 20 slabs per gradient summed to one K/V head
+    ("f16", 2, 2, 2500, 100, 128, True, True, 8, False),        # key mask, 256-byte rows
+    ("bf16", 1, 8, 2048, 2048, 128, False, True, 8, True),      # C5's shape at batch 1: 64 pairs, causal
+])
+def test_split_query_dkv_single_headed_kv(dtype, B, H, N, M, D, use_mask, l2norm, groups, causal):
+    """Single-headed K/V with a split dK/dV launch (round 6): the per-head f32 slabs become heads x splits slabs, one finalize launch sums them."""
+    _split_forward_case(dtype, B, H, N, M, D, use_mask, True, l2norm, groups, causal, fwd_split=False)
+
+
+def _split_forward_case(dtype, B, H, N, M, D, use_mask, single_kv, l2norm, groups, causal, fwd_split=True):
     import flash_cosine_sim_attention_amd as F
     from flash_cosine_sim_attention_amd import _lib
     dt = DT[dtype]
     prob = _lib.problem(dt, (B, H, 1 if single_kv else H, N, M, D), causal, False, l2norm, groups, 8.0 if l2norm else 0.125)
-    assert _lib.load().fcsa_forward_workspace_bytes(C.byref(prob)) > 0, "case would not take the split-key path"
+    assert not fwd_split or _lib.load().fcsa_forward_workspace_bytes(C.byref(prob)) > 0, "case would not take the split-key path"
+    if single_kv and not fwd_split:   # single-headed K/V: heads slabs per gradient without a split, heads x splits with one
+        assert _lib.load().fcsa_backward_workspace_bytes(C.byref(prob)) > (B * H * N * 4 + 255) // 256 * 256 + 2 * ((B * H * M * D * 4 + 255) // 256 * 256), \
+            "case would not split the backward"
     if causal and not single_kv:      # the causal cases also run the split-key dQ / split-query dK/dV kernels (f32 slabs behind delta in the workspace)
         assert _lib.load().fcsa_backward_workspace_bytes(C.byref(prob)) > (B * H * N * 4 + 255) // 256 * 256, "case would not split the backward"
     g = torch.Generator(device="cuda").manual_seed(N * 7 + M)
