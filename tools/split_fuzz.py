@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the split forms (round 6: split-key forward + combine, split-key dQ, split-query dK/dV, and their causal
+window forms) against the UN-split forms of the same library, on the sweep build (libfcsa_hip_sweep.so: `-DFCSA_VAR_SPLIT_ENV`,
+the split counts of a call come from FCSA_SPLITS / FCSA_KSPLIT / FCSA_DQ_SPLITS / FCSA_DKV_SPLITS; the product build has no such hook
+and picks the counts from its cost model, so ragged shapes with FORCED counts reach window / tail cases the product's own choice of
+count rarely produces).  Per configuration: one forward + backward with every count forced to 1, one with random counts; o, dq, dk, dv
+must agree to the reordering of f32 partial sums: |a - b| <= 2 ulp(b) + 1e-4 max|b| (16 bit; f32: 2e-5 max|b|).  A window that drops
+or repeats one 128-position tile moves whole rows by far more.
+usage: split_fuzz.py [--seed S] [--count K]        (measurement / verification tool, not part of the product path)"""
+import os, sys, argparse, ctypes, random, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flash_cosine_sim_attention_amd as F
+from flash_cosine_sim_attention_amd import _lib, _torch_ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--count", type=int, default=120)
+a = ap.parse_args()
+_torch_ops.load()
+binding = ctypes.CDLL(_torch_ops.BINDING_PATH)
+path = os.path.join(ROOT, "flash_cosine_sim_attention_amd", "libfcsa_hip_sweep.so")
+lib = ctypes.CDLL(path)
+lib.fcsa_last_error.restype = ctypes.c_char_p
+_lib._lib = lib
+assert binding.fcsa_torch_use_library(path.encode()) == 0
+
+VARS = ("FCSA_SPLITS", "FCSA_KSPLIT", "FCSA_DQ_SPLITS", "FCSA_DKV_SPLITS")
+EPS = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
+
+
+def step(q, k, v, do, env, **kw):
+    for n in VARS: os.environ.pop(n, None)
+    os.environ.update(env)
+    for t in (q, k, v): t.grad = None
+    o = F.flash_cosine_sim_attention(q, k, v, **kw)
+    o.backward(do)
+    torch.cuda.synchronize()
+    return [o.detach().float().clone()] + [t.grad.float().clone() for t in (q, k, v)]
+
+
+rng = random.Random(a.seed)
+bad = 0
+worst = {}
+for i in range(a.count):
+    dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
+    causal = rng.random() < 0.6 and dt != torch.float32      # (causal problems split at 16 bit only)
+    D = rng.choice([16, 32, 64, 64, 96, 128, 128])
+    B, H = rng.choice([1, 1, 2]), rng.choice([1, 2, 3])
+    lo, hi = (256, 2800) if causal else (64, 2800)
+    N, M = rng.randint(lo, hi), rng.randint(max(lo, 256), hi)
+    if causal and rng.random() < 0.5: M = N
+    if rng.random() < 0.2: N = (N + 127) // 128 * 128
+    if rng.random() < 0.2: M = (M + 127) // 128 * 128
+    single = rng.random() < 0.3
+    use_mask = rng.random() < 0.3
+    groups = rng.choice([1, 1, 1, 2]) if D >= 32 else 1
+    g = torch.Generator(device="cuda").manual_seed(1000 * a.seed + i)
+    q = torch.randn(B, H, N, D, device="cuda", dtype=dt, generator=g).requires_grad_()
+    kshape = (B, M, D) if single else (B, H, M, D)
+    k = torch.randn(kshape, device="cuda", dtype=dt, generator=g).requires_grad_()
+    v = torch.randn(kshape, device="cuda", dtype=dt, generator=g).requires_grad_()
+    do = torch.randn(B, H, N, D, device="cuda", dtype=dt, generator=g)
+    mask = (torch.rand(B, M, device="cuda", generator=g) > 0.3) if use_mask else None
+    kw = dict(mask=mask, causal=causal, scale=rng.choice([1, 8, 8]) if groups == 1 else 4, groups=groups)
+    forced = {"FCSA_SPLITS": str(rng.randint(1, 8)), "FCSA_KSPLIT": rng.choice("01"),
+              "FCSA_DQ_SPLITS": str(rng.randint(1, 8)), "FCSA_DKV_SPLITS": str(rng.randint(1, 8))}
+    desc = f"#{i} {str(dt)[6:]} B{B} H{H} N{N} M{M} D{D} causal={int(causal)} single={int(single)} mask={int(use_mask)} groups={groups} scale={kw['scale']} {forced}"
+    try:
+        ref = step(q, k, v, do, {n: "1" for n in VARS if n != "FCSA_KSPLIT"}, **kw)
+        got = step(q, k, v, do, forced, **kw)
+    except Exception as ex:      # an unsupported combination is an error of the fuzz's generator, not a pass
+        print("ERROR", desc, str(ex)[:200]); bad += 1; continue
+    fails = []
+    for name, r, x in zip(("o", "dq", "dk", "dv"), ref, got):
+        mx = r.abs().max().item()
+        tol = (2 * EPS[dt] * r.abs() + 1e-4 * mx) if dt in EPS else torch.full_like(r, 2e-5 * mx + 1e-9)
+        d = (x - r).abs()
+        if not torch.isfinite(x).all() or (d > tol).any():
+            fails.append(f"{name}: max|d| {d.max().item():.3g} (max|ref| {mx:.3g}), {(d > tol).sum().item()} of {d.numel()} outside")
+        w = (d / (tol + 1e-30)).max().item()
+        worst[name] = max(worst.get(name, 0.0), w)
+    if fails:
+        bad += 1
+        print("FAIL", desc, "|", "; ".join(fails), flush=True)
+for n in VARS: os.environ.pop(n, None)
+print(f"seed {a.seed}: {a.count} configurations, {bad} failed; worst |d| / bound: " + ", ".join(f"{k} {v:.2f}" for k, v in worst.items()))
+sys.exit(1 if bad else 0)
