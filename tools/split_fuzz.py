@@ -4,8 +4,11 @@ window forms) against the UN-split forms of the same library, on the sweep build
 the split counts of a call come from FCSA_SPLITS / FCSA_KSPLIT / FCSA_DQ_SPLITS / FCSA_DKV_SPLITS; the product build has no such hook
 and picks the counts from its cost model, so ragged shapes with FORCED counts reach window / tail cases the product's own choice of
 count rarely produces).  Per configuration: one forward + backward with every count forced to 1, one with random counts; o, dq, dk, dv
-must agree to the reordering of f32 partial sums: |a - b| <= 2 ulp(b) + 1e-4 max|b| (16 bit; f32: 2e-5 max|b|).  A window that drops
-or repeats one 128-position tile moves whole rows by far more.
+must agree to the reordering of f32 partial sums: |a - b| <= 2 ulp(b) + 1e-4 max|b| (16 bit; f32: 2e-5 max|b|) -- except for at most
+1e-4 of the elements, which may differ by up to 1e-2 max|b|: the split forward's 1/l differs from the un-split one's in its last f32 bits,
+which flips the 16-bit rounding of a P~ / dS operand element here and there, and ONE flipped dS element moves a dq / dk element by
+ulp(dS) * scale * |k^| ~ 1e-3 max|dq| (first run of this tool: 1 - 5 elements of 1e5 - 1e6 per tensor, every difference an exact power
+of two).  A window that drops or repeats one 128-position tile moves whole rows by far more than either bound.
 usage: split_fuzz.py [--seed S] [--count K]        (measurement / verification tool, not part of the product path)"""
 import os, sys, argparse, ctypes, random, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,7 +44,7 @@ def step(q, k, v, do, env, **kw):
 
 rng = random.Random(a.seed)
 bad = 0
-worst = {}
+worst, flips = {}, {}
 for i in range(a.count):
     dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
     causal = rng.random() < 0.6 and dt != torch.float32      # (causal problems split at 16 bit only)
@@ -53,7 +56,7 @@ for i in range(a.count):
     if rng.random() < 0.2: N = (N + 127) // 128 * 128
     if rng.random() < 0.2: M = (M + 127) // 128 * 128
     single = rng.random() < 0.3
-    use_mask = rng.random() < 0.3
+    use_mask = rng.random() < 0.3 and not causal      # (the reference contract: no key mask on causal calls)
     groups = rng.choice([1, 1, 1, 2]) if D >= 32 else 1
     g = torch.Generator(device="cuda").manual_seed(1000 * a.seed + i)
     q = torch.randn(B, H, N, D, device="cuda", dtype=dt, generator=g).requires_grad_()
@@ -76,13 +79,16 @@ for i in range(a.count):
         mx = r.abs().max().item()
         tol = (2 * EPS[dt] * r.abs() + 1e-4 * mx) if dt in EPS else torch.full_like(r, 2e-5 * mx + 1e-9)
         d = (x - r).abs()
-        if not torch.isfinite(x).all() or (d > tol).any():
-            fails.append(f"{name}: max|d| {d.max().item():.3g} (max|ref| {mx:.3g}), {(d > tol).sum().item()} of {d.numel()} outside")
+        out = (d > tol).sum().item()
+        if not torch.isfinite(x).all() or out > 1e-4 * d.numel() or d.max().item() > 1e-2 * mx:
+            fails.append(f"{name}: max|d| {d.max().item():.3g} (max|ref| {mx:.3g}), {out} of {d.numel()} outside")
+        flips[name] = flips.get(name, 0) + out
         w = (d / (tol + 1e-30)).max().item()
         worst[name] = max(worst.get(name, 0.0), w)
     if fails:
         bad += 1
         print("FAIL", desc, "|", "; ".join(fails), flush=True)
 for n in VARS: os.environ.pop(n, None)
-print(f"seed {a.seed}: {a.count} configurations, {bad} failed; worst |d| / bound: " + ", ".join(f"{k} {v:.2f}" for k, v in worst.items()))
+print(f"seed {a.seed}: {a.count} configurations, {bad} failed; worst |d| / tight bound: " + ", ".join(f"{k} {v:.2f}" for k, v in worst.items())
+      + "; elements outside the tight bound (operand-rounding flips): " + ", ".join(f"{k} {v}" for k, v in flips.items()))
 sys.exit(1 if bad else 0)
