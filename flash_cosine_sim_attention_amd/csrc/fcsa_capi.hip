@@ -261,6 +261,10 @@ int log2_blocks_per_group(const fcsa_problem& p) {     // log2(group size / 8), 
   if (dg % 8 != 0) return -1;
   int m = dg / 8, lg = 0;
   while ((1 << lg) < m) ++lg;
+  // ONE group over the whole head (groups = 1) may be any number of 8-blocks: the fused forms sum over the power-of-two lane / k-step
+  // block that contains the row, and the padding positions of that block contribute nothing (RowEpilogue: lanes c >= D / 8 hold 0;
+  // finish_q_frags: k-steps >= KS do not exist).  D = 96: 12 blocks -> 4.  (Round 6; until then D = 96 took the slab + finalize path.)
+  if (p.groups <= 1) return lg;
   return (1 << lg) == m ? lg : -1;
 }
 bool fusable_groups(const fcsa_problem& p) { return log2_blocks_per_group(p) >= 0; }

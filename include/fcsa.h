@@ -156,7 +156,7 @@ typedef struct fcsa_backward_args {
   void*           workspace;     /* >= fcsa_backward_workspace_bytes(&p) bytes, 256-byte aligned: delta [B,H,N] f32, plus f32
                                     slabs where an epilogue cannot finish the job -- partial dq of the split-key dQ kernel, partial
                                     dk / dv of the split-query dK/dV kernel and of single-headed K/V, l2norm groups that are not
-                                    8 * 2^k features wide.  The split forms also need dq (dk, dv) with stride0 == heads * stride1;
+                                    8 * 2^k features wide (one group over the whole head counts as fused at any D: D = 96).  The split forms also need dq (dk, dv) with stride0 == heads * stride1;
                                     other layouts run the unsplit kernels. */
   size_t          workspace_bytes;
   void*           stream;
@@ -178,7 +178,7 @@ size_t fcsa_forward_workspace_bytes(const fcsa_problem* p);
 
 /* 1 if fcsa_forward needs the norm.qn buffer for this problem, else 0.  It always does when a backward follows
  * (`need_backward`: qn is saved state) or l2norm_qk is off (unused then); an inference call needs it only where q is
- * normalised by the row kernel (float32, or group sizes that are not 8 * 2^k features) -- the 16-bit forward kernels
+ * normalised by the row kernel (float32, or several groups that are not 8 * 2^k features wide) -- the 16-bit forward kernels
  * normalise q in registers and then write NOTHING but `o` (the reference's need_store_rowsum == false path, cu:1086). */
 int fcsa_forward_needs_qn(const fcsa_problem* p, int32_t need_backward);
 

@@ -117,6 +117,10 @@ def test_backward_workspace_formula(lib):
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4)
     p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=D, l2norm_qk=1, groups=2)
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4)                      # fused epilogues
+    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=96, l2norm_qk=1, groups=1)   # ONE group of 12 blocks: fused (round 6)
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4)
+    p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=96, l2norm_qk=1, groups=2)   # groups of 6 blocks: slabs
+    assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + al(B * H * N * 96 * 4) + al(B * H * M * 96 * 4)
     p = _problem(batch=B, heads=H, kv_heads=H, q_len=N, k_len=M, dim_head=96, l2norm_qk=1, groups=8)   # group size 12
     assert lib.fcsa_backward_workspace_bytes(C.byref(p)) == al(B * H * N * 4) + al(B * H * N * 96 * 4) + al(B * H * M * 96 * 4)
     p = _problem(batch=B, heads=H, kv_heads=1, q_len=N, k_len=M, dim_head=D)

@@ -315,6 +315,15 @@ NAMED_CASES = [
     _named("K27_f16_d32_bias_mask", dtype="f16", groups=2, D=32, N=600, M=330, mask=True, bias=True, seed=227),
     _named("K28_bf16_d16_causal_m_gt_n", groups=1, D=16, N=520, M=700, causal=True, seed=228),
     _named("K29_f16_d16_online_ragged", dtype="f16", groups=2, scale=8.0, D=16, N=1000, M=129, seed=229),
+    # D = 96 with ONE l2norm group (12 eight-feature blocks: not a power of two).  Since round 6 the q-l2norm is fused into the forward prologue
+    # and the l2norm backward into the dQ / dK epilogues for it as well (the 16-lane block that holds a row has four padding lanes contributing
+    # nothing; fcsa_capi.hip log2_blocks_per_group) -- until then it took the row kernel for q and the f32 slabs + finalize.  Groups of 48
+    # features (96 / 2) still take those, and single-headed K/V keeps the slab for dk (head reduction).
+    _named("K30_bf16_d96_one_group_ragged", groups=1, D=96, N=333, M=515, B=2, H=3, seed=230),
+    _named("K31_f32_d96_one_group_causal", dtype="f32", groups=1, D=96, N=200, M=200, causal=True, seed=231),
+    _named("K32_f16_d96_one_group_mask_single_kv", dtype="f16", groups=1, D=96, N=260, M=300, mask=True, single_kv=True, H=3, seed=232),
+    _named("K33_bf16_d96_one_group_bias_causal", groups=1, D=96, N=300, M=300, causal=True, bias=True, seed=233),
+    _named("K34_bf16_d96_two_groups_slab_path", groups=2, scale=4.0, D=96, N=300, M=200, seed=234),
 ]
 
 

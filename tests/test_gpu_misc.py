@@ -13,10 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("d,groups", [(64, 1), (64, 8), (128, 2), (96, 3), (96, 4), (32, 1), (16, 2), (48, 3)])
+@pytest.mark.parametrize("d,groups", [(64, 1), (64, 8), (128, 2), (96, 1), (96, 2), (96, 3), (96, 4), (32, 1), (16, 2), (48, 3)])
 def test_fcsa_l2norm_entry_vs_oracle(dtype, d, groups):
     """fcsa_l2norm (the public l2norm_tensors as a C entry point): xn and the saved inverse norms, incl. group sizes that are
-    not 8 * 2^k (96 / 4 = 24, 96 / 3 = 32, 48 / 3 = 16) and a strided input view."""
+    not 8 * 2^k (96 / 4 = 24, 96 / 3 = 32, 48 / 3 = 16; 96 / 1 and 96 / 2: 12 and 6 lanes per group -- butterfly over the power-of-two part,
+    the odd factor gathered) and a strided input view."""
     import ctypes as C
     from flash_cosine_sim_attention_amd import ext, _lib
     from oracle import cosine_sim_oracle as O
