@@ -59,16 +59,20 @@ for i in range(a.count):
     use_mask = rng.random() < 0.3 and not causal      # (the reference contract: no key mask on causal calls)
     groups = rng.choice([1, 1, 1, 2]) if D >= 32 else 1
     g = torch.Generator(device="cuda").manual_seed(1000 * a.seed + i)
-    q = torch.randn(B, H, N, D, device="cuda", dtype=dt, generator=g).requires_grad_()
+    strided = rng.random() < 0.3          # q, k, v as `b h n d` views of `b n (h d)` memory (the module glue's layout)
+    def make(shape):
+        if strided and len(shape) == 4:
+            return torch.randn(shape[0], shape[2], shape[1], shape[3], device="cuda", dtype=dt, generator=g).transpose(1, 2).requires_grad_()
+        return torch.randn(shape, device="cuda", dtype=dt, generator=g).requires_grad_()
+    q = make((B, H, N, D))
     kshape = (B, M, D) if single else (B, H, M, D)
-    k = torch.randn(kshape, device="cuda", dtype=dt, generator=g).requires_grad_()
-    v = torch.randn(kshape, device="cuda", dtype=dt, generator=g).requires_grad_()
+    k, v = make(kshape), make(kshape)
     do = torch.randn(B, H, N, D, device="cuda", dtype=dt, generator=g)
     mask = (torch.rand(B, M, device="cuda", generator=g) > 0.3) if use_mask else None
     kw = dict(mask=mask, causal=causal, scale=rng.choice([1, 8, 8]) if groups == 1 else 4, groups=groups)
     forced = {"FCSA_SPLITS": str(rng.randint(1, 8)), "FCSA_KSPLIT": rng.choice("01"),
               "FCSA_DQ_SPLITS": str(rng.randint(1, 8)), "FCSA_DKV_SPLITS": str(rng.randint(1, 8))}
-    desc = f"#{i} {str(dt)[6:]} B{B} H{H} N{N} M{M} D{D} causal={int(causal)} single={int(single)} mask={int(use_mask)} groups={groups} scale={kw['scale']} {forced}"
+    desc = f"#{i} {str(dt)[6:]} B{B} H{H} N{N} M{M} D{D} causal={int(causal)} single={int(single)} mask={int(use_mask)} strided={int(strided)} groups={groups} scale={kw['scale']} {forced}"
     try:
         ref = step(q, k, v, do, {n: "1" for n in VARS if n != "FCSA_KSPLIT"}, **kw)
         got = step(q, k, v, do, forced, **kw)
