@@ -372,6 +372,17 @@ def main():
                     hit = (os.path.relpath(tfile, ROOT), tk, rec.get("derived", {}).get(dom["name"] + "_kernel"))
                     break
             if hit:
+                # north_star: "rocprof-reported HBM GB/s": the PMC bytes of EVERY kernel of the step over this run's event-timed
+                # launch durations (peak 8 TB/s); the l2norm pass is the one HBM-bound kernel of the step
+                rec_k = json.load(open(os.path.join(ROOT, hit[0]))).get("kernels", {})
+                hbm = {}
+                for name, kst in kernels.items():
+                    tk2 = rec_k.get(name + "_kernel")
+                    if tk2 and kst["avg_us"] > 0:
+                        gbps = tk2["total_bytes"] / (kst["avg_us"] * 1e-6) / 1e9
+                        hbm[name] = {"bytes_per_launch": round(tk2["total_bytes"]), "avg_us": kst["avg_us"], "GB/s": round(gbps, 1),
+                                     "frac_of_8TBps": round(gbps / 8000.0, 4)}
+                roofline["hbm"] = hbm
                 roofline["traffic"] = round(hit[1]["total_bytes"])
                 roofline["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; measured on a build of the same "
                                               "kernel sources + Makefile, source sha256 %s)" % (hit[0], src[:12]))

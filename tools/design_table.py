@@ -29,6 +29,8 @@ if derived:
     L.append(f"| matrix-pipe occupancy in REAL clocks (`SQ_VALU_MFMA_BUSY_CYCLES` ÷ (4 SIMDs × 256 CUs × `GRBM_GUI_ACTIVE` per XCD)) and effective clock (`GRBM_GUI_ACTIVE` per XCD ÷ kernel-trace duration) | {cell} — the 2.5 PFLOP/s peak is quoted at 2.4 GHz | `profiles/{tag}_pmc_summary.txt`, bench line `roofline.mfma_busy` |")
 tot = sum(v["total_bytes"] for v in tr.values()) / 1e6
 L.append(f"| HBM traffic per launch (PMC, FETCH_SIZE×2 + WRITE_SIZE, keyed on the hash of the kernel sources + Makefile) vs algorithmic | l2norm {tr['l2norm_kernel']['total_bytes'] / 1e6:.1f} MB (33.5), fwd {tr['fwd_kernel']['total_bytes'] / 1e6:.1f} (84), dq {tr['bwd_dq_kernel']['total_bytes'] / 1e6:.1f} (101), dkv {tr['bwd_dkv_kernel']['total_bytes'] / 1e6:.1f} (101): {tot:.0f} MB per step vs SURVEY §8(d)'s 202 MB minimum (the saved c1·q̂ / k̂ and the dQ kernel's second read of K, V) at {tot / 1e6 / (d['ms_per_step'] * 1e-3):.1f} TB/s — not binding | `profiles/{tag}_pmc_traffic.json`, `{tag}_pmc_summary.txt` |")
+hb = d["roofline"].get("hbm")
+if hb: L.append("| HBM GB/s per kernel (PMC bytes ÷ this run's event-timed launch, peak 8 TB/s) | " + ", ".join(f"`{k}` {v['GB/s'] / 1e3:.2f} TB/s ({v['frac_of_8TBps']:.2f})" for k, v in hb.items()) + " — only the k-l2norm pass is HBM-bound | bench line `roofline.hbm` |")
 L.append(f"| accuracy at C3 (rel-L2 vs float64 on the same bf16 inputs) | o {acc['hip']['o']['rel_l2']:.1e}, dq {acc['hip']['dq']['rel_l2']:.1e}, dk {acc['hip']['dk']['rel_l2']:.1e}, dv {acc['hip']['dv']['rel_l2']:.1e}; PyTorch composite in bf16: {acc['torch_same_dtype']['o']['rel_l2']:.1e} / {acc['torch_same_dtype']['dq']['rel_l2']:.1e} / {acc['torch_same_dtype']['dk']['rel_l2']:.1e} / {acc['torch_same_dtype']['dv']['rel_l2']:.1e} | bench line `accuracy` |")
 L.append(f"| C2 (B4 H8 N1024 D64 f16 fwd) | {c['C2']['fwd_ms']} ms, {c['C2']['fwd_tflops']} TFLOP/s, {c['C2']['vs_flash_sdpa']}× SDPA | bench line `configs` |")
 L.append(f"| C4 (cross-attention, key mask, f16) | fwd {c['C4']['fwd_ms']} ms, fwd + bwd {c['C4']['ms']} ms = {c['C4']['tflops']} TFLOP/s, {c['C4']['vs_flash_sdpa']}× SDPA | |")
