@@ -373,6 +373,8 @@ int fcsa_debug_forward_form(int32_t form) { return fcsa::forward_wide128_mode(fo
 int fcsa_l2norm(int32_t dtype, int32_t batch, int32_t heads, int32_t len, int32_t dim_head, int32_t groups,
                 const fcsa_tensor* x, void* xn, float* inv_norm, void* stream) {
   if (dtype != FCSA_F16 && dtype != FCSA_BF16 && dtype != FCSA_F32) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dtype %d not supported", dtype);
+  if (batch < 0 || heads < 0 || len < 0) return fail(FCSA_ERR_INVALID_ARG, "fcsa_l2norm: negative size (B=%d H=%d L=%d)", batch, heads, len);
+  if (batch == 0 || heads == 0 || len == 0) return FCSA_OK;      // no row: nothing to launch (empty tensors carry NULL pointers)
   if (x == nullptr || xn == nullptr) return fail(FCSA_ERR_INVALID_ARG, "fcsa_l2norm: null argument");
   if (dim_head <= 0 || dim_head % 8 != 0) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dim_head %d must be a multiple of 8", dim_head);
   if (dim_head > 512) return fail(FCSA_ERR_UNSUPPORTED, "fcsa_l2norm: dim_head %d > 512", dim_head);
@@ -425,12 +427,41 @@ size_t fcsa_forward_workspace_bytes(const fcsa_problem* p) {
   return align256(rows * p->dim_head * 4) + align256(rows * 4);
 }
 
+// Zero-size problems (empty tensors: what torch hands over has NULL data pointers then).  batch, heads or q_len == 0: the forward has no
+// output element; k_len == 0: every query row is a row without a valid key, for which the kernels' semantics are o = 0 (cu:1239) and
+// finite (zero) gradients.  Nothing is launched; the outputs that DO have elements are zero-filled on the caller's stream, row by row
+// (any strides).  The reference launches a zero-sized grid there (a CUDA error it prints and ignores, cu:17-28).
+static int zero_rows(const char* name, const fcsa_tensor& t, int es, int B, int H, int L, int D, hipStream_t s) {
+  if (B <= 0 || H <= 0 || L <= 0) return FCSA_OK;
+  if (int rc = check_tensor(name, t, es, true)) return rc;
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < H; ++h) {
+      char* base = static_cast<char*>(t.ptr) + ((int64_t)b * t.stride0 + (int64_t)h * t.stride1) * es;
+      const hipError_t e = t.stride2 == D ? hipMemsetAsync(base, 0, (size_t)L * D * es, s)
+                                          : hipMemset2DAsync(base, (size_t)t.stride2 * es, 0, (size_t)D * es, (size_t)L, s);
+      if (e != hipSuccess) return fail(FCSA_ERR_LAUNCH, "%s: zero fill failed: %s", name, hipGetErrorString(e));
+    }
+  return FCSA_OK;
+}
+
 int fcsa_forward(const fcsa_forward_args* a) {
   if (a == nullptr) return fail(FCSA_ERR_INVALID_ARG, "null args");
   const fcsa_problem& p = a->p;
   if (int rc = check_problem(p)) return rc;
   if (p.causal && a->mask != nullptr) return fail(FCSA_ERR_INVALID_ARG, "mask should not be given if causal (cu:1675)");
   const int es = elem_size(p.dtype);
+  if (p.batch == 0 || p.heads == 0 || p.q_len == 0) return FCSA_OK;      // no output element (k-side saved state is not needed by a backward either)
+  if (p.k_len == 0) {                                                     // rows without a key: o = 0; inv_l = 1 (never read: the backward below has no key to visit)
+    hipStream_t s0 = static_cast<hipStream_t>(a->stream);
+    if (int rc = zero_rows("o", a->o, es, p.batch, p.heads, p.q_len, p.dim_head, s0)) return rc;
+    if (a->inv_l != nullptr) {
+      const float one = 1.f;
+      uint32_t bits; memcpy(&bits, &one, 4);
+      if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->inv_l), (int)bits, (size_t)p.batch * p.heads * p.q_len, s0) != hipSuccess)
+        return fail(FCSA_ERR_LAUNCH, "inv_l: fill failed");
+    }
+    return FCSA_OK;
+  }
   if (int rc = check_tensor("q", a->q, es, true)) return rc;
   if (int rc = check_tensor("k", a->k, es, true)) return rc;
   if (int rc = check_tensor("v", a->v, es, true)) return rc;
@@ -516,6 +547,13 @@ int fcsa_backward(const fcsa_backward_args* a) {
   if (int rc = check_problem(p)) return rc;
   if (p.causal && a->mask != nullptr) return fail(FCSA_ERR_INVALID_ARG, "mask should not be given if causal (cu:1675)");
   const int es = elem_size(p.dtype);
+  if (p.batch == 0 || p.heads == 0) return FCSA_OK;                        // every gradient is empty
+  if (p.q_len == 0 || p.k_len == 0) {                                      // no (query, key) pair: the gradients that have elements are zero (d_bias has none)
+    hipStream_t s0 = static_cast<hipStream_t>(a->stream);
+    if (int rc = zero_rows("dq", a->dq, es, p.batch, p.heads, p.q_len, p.dim_head, s0)) return rc;
+    if (int rc = zero_rows("dk", a->dk, es, p.batch, p.kv_heads, p.k_len, p.dim_head, s0)) return rc;
+    return zero_rows("dv", a->dv, es, p.batch, p.kv_heads, p.k_len, p.dim_head, s0);
+  }
   if (int rc = check_tensor("d_out", a->d_out, es, true)) return rc;
   if (int rc = check_tensor("o", a->o, es, true)) return rc;
   if (int rc = check_tensor("v", a->v, es, true)) return rc;

@@ -54,6 +54,8 @@ def l2norm_device(t: torch.Tensor, groups: int = 1) -> torch.Tensor:
     lib = _lib.load()
     shape = t.shape
     D = shape[-1]
+    if t.numel() == 0:
+        return torch.empty_like(t)
     t4 = t.reshape(1, 1, -1, D) if t.dim() < 4 else t.reshape(-1, shape[-3], shape[-2], D)
     if t4.stride(-1) != 1 or t4.data_ptr() % 16 or any(s % (16 // t4.element_size()) for s in t4.stride()[:-1]):
         t4 = t4.contiguous()

@@ -162,7 +162,10 @@ typedef struct fcsa_backward_args {
   void*           stream;
 } fcsa_backward_args;
 
-/* Replaces flash_cosine_sim_attention_forward (cu:1630-1748). */
+/* Replaces flash_cosine_sim_attention_forward (cu:1630-1748).
+ * Zero-size problems launch nothing: batch, heads or q_len == 0 return FCSA_OK untouched (pointers of empty tensors may be NULL);
+ * k_len == 0 makes every row a row without a valid key: o is zero-filled on the stream (inv_l = 1).  fcsa_backward likewise:
+ * q_len == 0 or k_len == 0 zero-fills whichever of dq / dk / dv has elements.  (The reference launches an empty grid there.) */
 int fcsa_forward(const fcsa_forward_args* args);
 
 /* Replaces flash_cosine_sim_attention_backward (cu:1752-1917): delta pre-pass (cu:1256-1335)

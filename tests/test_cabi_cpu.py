@@ -344,3 +344,14 @@ def test_package_carries_its_own_header_and_imports_without_the_repository(tmp_p
     assert out.returncode == 0, out.stderr[-2000:]
     from flash_cosine_sim_attention_amd import _lib
     assert int(out.stdout.strip()) == _lib.ABI_VERSION
+
+
+def test_zero_size_problems_return_ok_without_touching_anything(lib):
+    """batch, heads or q_len == 0: no output element exists -- FCSA_OK before any pointer is looked at or anything is launched (this
+    runs without a GPU); torch hands NULL data pointers over for empty tensors."""
+    from flash_cosine_sim_attention_amd import _lib
+    for kw in (dict(batch=0), dict(heads=0, kv_heads=0), dict(q_len=0)):
+        a = _fwd_args(_problem(**kw))
+        a.q = a.k = a.v = a.o = _lib.Tensor(None, 0, 0, 0)
+        assert lib.fcsa_forward(C.byref(a)) == 0, lib.fcsa_last_error()
+    assert lib.fcsa_forward_workspace_bytes(C.byref(_problem(q_len=0))) == 0

@@ -331,3 +331,37 @@ def test_python_autograd_function_golden(name):
         for other in ("q", "k", "v", "bias"):
             if other != need:
                 assert got[other] is None, (need, other)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("what", ["N=0", "M=0", "B=0", "N=0,M=0", "M=0 single-kv causal", "N=0 mask bias"])
+def test_zero_size_inputs(dtype, what):
+    """Empty tensors (torch hands NULL data pointers over): nothing is launched (include/fcsa.h, fcsa_forward).  No query -> empty o and
+    zero dk / dv; no key -> every row is a row without a valid key: o == 0 exactly (kernel semantics, cu:1239), dq == 0.  The reference
+    launches an empty grid there (a CUDA error it prints and ignores)."""
+    import flash_cosine_sim_attention_amd as F
+    B, H, N, M, D = 2, 3, 5, 7, 64
+    if what.startswith("N=0"): N = 0
+    if "M=0" in what: M = 0
+    if what == "B=0": B = 0
+    single, causal = "single-kv" in what, "causal" in what
+    q = torch.randn(B, H, N, D, device="cuda", dtype=dtype, requires_grad=True)
+    ks = (B, M, D) if single else (B, H, M, D)
+    k = torch.randn(ks, device="cuda", dtype=dtype, requires_grad=True)
+    v = torch.randn(ks, device="cuda", dtype=dtype, requires_grad=True)
+    kw = dict(causal=causal)
+    bias = None
+    if "mask" in what: kw["mask"] = torch.ones(B, M, device="cuda", dtype=torch.bool)
+    if "bias" in what:
+        bias = torch.randn(H, N, M, device="cuda", dtype=dtype, requires_grad=True)
+        kw["attn_bias"] = bias
+    o = F.flash_cosine_sim_attention(q, k, v, **kw)
+    assert o.shape == q.shape and o.dtype == dtype
+    assert torch.equal(o, torch.zeros_like(o))
+    o.backward(torch.ones_like(o))
+    for t in (q, k, v):
+        assert t.grad is not None and t.grad.shape == t.shape and torch.equal(t.grad, torch.zeros_like(t))
+    if bias is not None:
+        assert bias.grad.shape == bias.shape
+    with torch.no_grad():          # the inference path (nothing saved)
+        assert torch.equal(F.flash_cosine_sim_attention(q, k, v, **kw), torch.zeros_like(q))
