@@ -711,6 +711,17 @@ int fcsa_backward(const fcsa_backward_args* a) {
       if (int rc = timed("finalize", "finalize dv", s, [&] { return fcsa::launch_l2norm_bwd(p.dtype, nv, s); })) return rc;
     }
   }
+  // Two degenerate problems whose dq and dk are EXACTLY zero, and for which the kernels' arithmetic is not meaningful:
+  //   scale == 0: the logits do not depend on q, k.  The kernels carry c1 = scale * log2(e) folded into the saved q^ and undo it with
+  //     1 / c1 in the l2norm backward and the dK^ epilogue: 0 * inf = NaN.
+  //   l2norm groups of ONE feature (groups == dim_head): x^ = sign(x), whose derivative is zero; the tangent-space projection
+  //     r (g - x^ <g, x^>) is then a pure cancellation that the 16-bit rounding of c1 * q^ leaves at 2^-11 |g| / |x| -- unbounded for
+  //     elements near zero (measured 0.7 against an exact 0).
+  // The reference's autograd through F.normalize / scale * sim gives zeros in both; dv (and d_bias) are what the kernels wrote.
+  if (p.scale == 0.f || (p.l2norm_qk && p.groups == p.dim_head)) {
+    if (int rc = zero_rows("dq", a->dq, es, p.batch, p.heads, p.q_len, p.dim_head, s)) return rc;
+    if (int rc = zero_rows("dk", a->dk, es, p.batch, p.kv_heads, p.k_len, p.dim_head, s)) return rc;
+  }
   return FCSA_OK;
 }
 

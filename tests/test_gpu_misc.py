@@ -420,3 +420,34 @@ def test_concurrent_host_threads_on_their_own_streams():
     for t in threads: t.join()
     torch.cuda.synchronize()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("what", ["scale=0", "scale=0 no-l2norm causal", "groups=D", "groups=D single-kv"])
+def test_degenerate_problems_with_exactly_zero_dq_dk(dtype, what):
+    """scale == 0 (logits independent of q, k: uniform attention) and l2norm groups of one feature (x^ = sign(x)): dq and dk are exactly
+    zero, as the reference's autograd gives them; the kernels' own arithmetic there is 0 * inf (1 / c1) resp. a pure cancellation amplified
+    by 1 / |x| (fcsa_capi.hip, end of fcsa_backward).  o and dv are ordinary results and are held against float32 math."""
+    import flash_cosine_sim_attention_amd as F
+    torch.manual_seed(11)
+    B, H, N, M, D = 2, 3, 70, 90, 16
+    single = "single-kv" in what
+    q = torch.randn(B, H, N, D, device="cuda", dtype=dtype)
+    ks = (B, M, D) if single else (B, H, M, D)
+    k, v = torch.randn(ks, device="cuda", dtype=dtype), torch.randn(ks, device="cuda", dtype=dtype)
+    kw = dict(scale=0.0) if what.startswith("scale=0") else dict(scale=1.0, groups=D)
+    if "no-l2norm" in what:
+        kw.update(l2norm_qk=False, causal=True)
+        q, k = (torch.nn.functional.normalize(t.float(), dim=-1).to(dtype) for t in (q, k))
+    for t in (q, k, v): t.requires_grad_()
+    do = torch.randn(B, H, N, D, device="cuda", dtype=dtype)
+    o = F.flash_cosine_sim_attention(q, k, v, **kw)
+    o.backward(do)
+    assert torch.equal(q.grad, torch.zeros_like(q)) and torch.equal(k.grad, torch.zeros_like(k))
+    qf, kf, vf = (t.detach().float().requires_grad_() for t in (q, k, v))
+    of = F.plain_cosine_sim_attention(qf, kf, vf, **kw)
+    of.backward(do.float())
+    tol = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+    assert (o.float() - of).abs().max().item() <= tol
+    assert (v.grad.float() - vf.grad).abs().max().item() <= tol * max(1.0, vf.grad.abs().max().item())
+    assert qf.grad.abs().max().item() <= 2e-3 and kf.grad.abs().max().item() <= 2e-3      # (the float32 reference's own residue of an exact zero)
