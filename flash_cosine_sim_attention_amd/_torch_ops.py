@@ -47,7 +47,8 @@ def _register_fakes():
         none32, none = q.new_empty((0,), dtype=torch.float32), q.new_empty((0,))
         inv_l = torch.empty((B, H, N), **f32) if need_backward else none32
         # (an inference call of the 16-bit kernels saves no normalised q: fcsa_forward_needs_qn, include/fcsa.h)
-        fusable = D % groups == 0 and (D // groups) % 8 == 0 and ((D // groups) // 8) & ((D // groups) // 8 - 1) == 0
+        blocks = (D // groups) // 8          # fcsa_capi.hip log2_blocks_per_group: 8 * 2^k features per group, or ONE group of any width (D = 96)
+        fusable = D % groups == 0 and (D // groups) % 8 == 0 and (blocks & (blocks - 1) == 0 or groups == 1)
         qn = q.new_empty((B, H, N, D)) if (l2norm_qk and (need_backward or q.dtype == torch.float32 or not fusable)) else none
         kn = q.new_empty((B, Hk, M, D)) if l2norm_qk else none
         rq = torch.empty((B, H, N, groups), **f32) if (l2norm_qk and need_backward) else none32

@@ -451,3 +451,25 @@ def test_degenerate_problems_with_exactly_zero_dq_dk(dtype, what):
     assert (o.float() - of).abs().max().item() <= tol
     assert (v.grad.float() - vf.grad).abs().max().item() <= tol * max(1.0, vf.grad.abs().max().item())
     assert qf.grad.abs().max().item() <= 2e-3 and kf.grad.abs().max().item() <= 2e-3      # (the float32 reference's own residue of an exact zero)
+
+
+@pytest.mark.parametrize("dtype,D,groups,need_backward,kv3d", [
+    (torch.bfloat16, 64, 1, False, False), (torch.bfloat16, 64, 1, True, False), (torch.float16, 96, 1, False, False),      # D = 96, one group: fused since round 6 (no qn at inference)
+    (torch.float16, 96, 2, False, False), (torch.float32, 64, 1, False, False), (torch.bfloat16, 128, 8, True, True),
+    (torch.float16, 32, 4, False, True)])
+def test_fake_kernels_describe_the_real_outputs(dtype, D, groups, need_backward, kv3d):
+    """torch.compile traces the op through its fake kernels (_torch_ops.py): shapes, dtypes and devices of all six forward outputs -- incl.
+    WHICH saved tensors are empty for a problem, which follows fcsa_forward_needs_qn -- and of the backward's four must match what the
+    binding returns (torch.library.opcheck, test_faketensor)."""
+    import flash_cosine_sim_attention_amd as F      # noqa: F401 -- registers the ops and their fake kernels
+    torch.manual_seed(3)
+    B, H, N, M = 2, 3, 40, 50
+    q = torch.randn(B, H, N, D, device="cuda", dtype=dtype)
+    ks = (B, M, D) if kv3d else (B, H, M, D)
+    k, v = torch.randn(ks, device="cuda", dtype=dtype), torch.randn(ks, device="cuda", dtype=dtype)
+    args = (q, k, v, None, None, False, 4.0, False, True, groups, need_backward)
+    torch.library.opcheck(torch.ops.fcsa.forward.default, args, test_utils=("test_faketensor",))
+    if need_backward:
+        o, inv_l, qn, kn, rq, rk = torch.ops.fcsa.forward(*args)
+        bargs = (torch.randn_like(o), o, inv_l, q, k, v, None, None, qn, kn, rq, rk, False, 4.0, False, True, groups, False)
+        torch.library.opcheck(torch.ops.fcsa.backward.default, bargs, test_utils=("test_faketensor",))
