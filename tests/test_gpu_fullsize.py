@@ -292,3 +292,31 @@ def test_tensors_beyond_4_gib_address_the_last_head_correctly():
         for name, big, small in (("dq", q.grad, sq.grad), ("dk", k.grad, sk.grad), ("dv", v.grad, sv.grad)):
             rel = ((big[b, h].float() - small[0, 0].float()).norm() / small[0, 0].float().norm()).item()
             assert rel <= 1e-2, f"slice ({b}, {h}): {name} differs from the slice-only run by rel-L2 {rel:.3e}"
+
+
+def test_long_sequence_65536_sampled_rows_vs_float64():
+    """N = 65536, one head, causal, bf16 (512 row tiles: 256 balanced pairs; 16.8 MB per tensor): sampled query rows of o and sampled key
+    rows of dv against float64 math on the same inputs, row-wise, so the N x N logits never exist (tools/long_seq_probe.py does the same
+    up to N = 131072)."""
+    import flash_cosine_sim_attention_amd as F
+    N, D, dev = 65536, 64, "cuda"
+    g = torch.Generator(device=dev).manual_seed(65)
+    q, k, v, do = (torch.randn(1, 1, N, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(4))
+    for t in (q, k, v): t.requires_grad_()
+    o = F.flash_cosine_sim_attention(q, k, v, causal=True)
+    o.backward(do)
+    for t in (o, q.grad, k.grad, v.grad): assert torch.isfinite(t.float()).all()
+    qh = torch.nn.functional.normalize(q.detach().double()[0, 0], dim=-1)
+    kh = torch.nn.functional.normalize(k.detach().double()[0, 0], dim=-1)
+    vd, dod, od = v.detach().double()[0, 0], do.double()[0, 0], o.detach().double()[0, 0]
+    for i in (0, 1, 127, 128, 4095, N // 2 + 3, N - 129, N - 1):
+        p = torch.softmax(8.0 * (kh[: i + 1] @ qh[i]), dim=0)
+        assert ((p @ vd[: i + 1]) - od[i]).abs().max().item() <= 2e-2, i          # (bf16 output: measured 4e-3)
+    l = torch.empty(N, device=dev, dtype=torch.float64)
+    for a in range(0, N, 4096):
+        s = 8.0 * (qh[a:a + 4096] @ kh[: a + 4096].T)
+        idx = torch.arange(a, a + 4096, device=dev)[:, None]
+        l[a:a + 4096] = torch.logsumexp(s.masked_fill(torch.arange(s.shape[1], device=dev)[None, :] > idx, float("-inf")), dim=1)
+    for j in (0, 129, N // 2, N - 2):
+        pcol = torch.exp(8.0 * (qh[j:] @ kh[j]) - l[j:])
+        assert ((pcol @ dod[j:]) - v.grad.double()[0, 0, j]).abs().max().item() <= 5e-2, j      # (measured 1.1e-2 against |dv| up to 4)
