@@ -150,3 +150,84 @@ def test_arena_detects_a_stray_write():
     assert not ar.guards_intact()
     u = Arena(64 * 1024).take((10,), torch.bfloat16)
     assert not torch.isfinite(u.float()).any()          # the fill pattern reads as NaN in every float type the ABI takes
+
+
+PADDED = [
+    # id, dtype, B, H, Hk, N, M, D, kwargs -- every tensor of the call (inputs AND outputs) has rows of D + PAD elements and a head-major memory
+    # order ([H, B, N, D + PAD] storage viewed as [B, H, N, D]): the ABI takes element strides per tensor (include/fcsa.h, fcsa_tensor)
+    ("bf16_d64_causal_padded_rows", "bf16", 2, 3, 3, 200, 200, 64, dict(causal=True)),
+    ("f16_d128_mask_single_kv_padded", "f16", 2, 3, 1, 130, 300, 128, dict(mask=True)),
+    ("bf16_d96_padded", "bf16", 1, 2, 2, 140, 170, 96, dict()),
+    ("f32_d32_padded", "f32", 1, 2, 2, 100, 130, 32, dict(causal=True)),
+    ("bf16_d64_split_layout_padded", "bf16", 1, 2, 2, 40, 2500, 64, dict()),      # (a split-eligible problem: strided layouts must still be right, split or not)
+]
+
+
+@pytest.mark.parametrize("name,dtype,B,H,Hk,N,M,D,kw", PADDED, ids=[c[0] for c in PADDED])
+def test_strided_inputs_and_outputs_through_the_c_abi(name, dtype, B, H, Hk, N, M, D, kw):
+    """Strided o / dq / dk / dv (and inputs): the padding elements behind every row keep the arena's pattern, and the results equal the
+    contiguous call's (bit for bit where both calls take the same form)."""
+    from flash_cosine_sim_attention_amd import _lib
+    lib = _lib.load()
+    dt = DT[dtype]
+    PAD = 16
+    causal, mask = kw.get("causal", False), kw.get("mask", False)
+    prob = _lib.problem(dt, (B, H, Hk, N, M, D), causal, False, True, 1, 8.0)
+    fws_n = int(lib.fcsa_forward_workspace_bytes(C.byref(prob)))
+    bws_n = int(lib.fcsa_backward_workspace_bytes(C.byref(prob)))
+    es = torch.empty((), dtype=dt).element_size()
+    per = lambda h, l: B * h * l * (D + PAD) * es
+    ar = Arena(2 * (6 * per(H, N) + 7 * per(Hk, M) + (B * H * N * 2 + B * Hk * M) * 4 + fws_n + bws_n) + B * M + 80 * (GUARD + 256))
+    g = torch.Generator(device="cuda").manual_seed(hash(name) % 10000)
+    stream = torch.cuda.current_stream().cuda_stream
+    ptr = lambda t: None if t is None else t.data_ptr()
+
+    def padded(h, l):          # [B, h, l, D] view of [h, B, l, D + PAD] storage
+        return ar.take((h, B, l, D + PAD), dt).permute(1, 0, 2, 3)[..., :D]
+
+    def plain(h, l):
+        return ar.take((B, h, l, D), dt)
+
+    vals = [torch.randn((B, h, l, D), device="cuda", dtype=torch.float32, generator=g).to(dt) for h, l in ((H, N), (Hk, M), (Hk, M), (H, N))]
+    mk = None
+    if mask:
+        mk = ar.take((B, M), torch.bool)
+        mk.copy_(torch.rand((B, M), device="cuda", generator=g) > 0.3)
+        mk[:, 0] = True
+    results = []
+    for make in (plain, padded):
+        q, k, v, do = make(H, N), make(Hk, M), make(Hk, M), make(H, N)
+        for t, x in zip((q, k, v, do), vals): t.copy_(x)
+        o, dq, dk, dv = make(H, N), make(H, N), make(Hk, M), make(Hk, M)
+        inv_l = ar.take((B, H, N), torch.float32)
+        qn, kn = ar.take((B, H, N, D), dt), ar.take((B, Hk, M, D), dt)
+        rq, rk = ar.take((B, H, N, 1), torch.float32), ar.take((B, Hk, M, 1), torch.float32)
+        fws = ar.take((fws_n,), torch.uint8) if fws_n else None
+        ws = ar.take((max(bws_n, 1),), torch.uint8)
+        norm = _lib.NormState(ptr(qn), ptr(kn), ptr(rq), ptr(rk))
+        t4 = lambda t: _lib.Tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+        fa = _lib.ForwardArgs(prob, t4(q), t4(k), t4(v), t4(o), ptr(inv_l), ptr(mk), None, norm, ptr(fws), fws_n, stream)
+        _lib.check(lib.fcsa_forward(C.byref(fa)), "fcsa_forward")
+        ba = _lib.BackwardArgs(prob, t4(do), t4(o), ptr(inv_l), t4(q), t4(k), t4(v), ptr(mk), None, norm, t4(dq), t4(dk), t4(dv), None,
+                               ws.data_ptr(), bws_n, stream)
+        _lib.check(lib.fcsa_backward(C.byref(ba)), "fcsa_backward")
+        torch.cuda.synchronize()
+        results.append([t.clone() for t in (o, dq, dk, dv)])
+    # the padding behind every row was carved out of "used" ranges: check it explicitly, then the guards between buffers
+    raw = ar.buf
+    assert ar.guards_intact(), "a byte outside the call's buffers was written"
+    # padding columns of the padded tensors: re-derive them from the arena by scanning every (h, B, l, D + PAD) block taken by `padded`
+    for (off, n) in ar.used:
+        blk = raw[off:off + n]
+        for h, l in ((H, N), (Hk, M)):
+            if n == per(h, l):
+                pad = blk.view(dt).view(h, B, l, D + PAD)[..., D:].contiguous().view(torch.uint8)
+                assert bool((pad == FILL).all().item()), "a padding element behind a row was written"
+    for nm, a, b in zip(("o", "dq", "dk", "dv"), results[0], results[1]):
+        assert torch.isfinite(a.float()).all(), nm
+        # (bit-identical where both calls take the same form; a layout without stride0 == heads * stride1 runs the UN-split backward /
+        #  forward -- include/fcsa.h -- and then differs from the contiguous call's split form by the order of f32 partial sums)
+        rel = ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30)).item()
+        assert rel <= {"f32": 1e-5, "f16": 1e-3, "bf16": 6e-3}[dtype], f"{nm}: the strided call differs from the contiguous one (rel-L2 {rel:.2e})"
+        if "split" not in name and "single_kv" not in name:
+            assert torch.equal(a, b), f"{nm}: same form, but not bit-identical"
